@@ -1,0 +1,135 @@
+/*
+ * orbhip.h — C ABI of libORBhip, the MI355X (gfx950) ORB feature extractor.
+ *
+ * The reference has no FFI layer: its boundary for this path is the C++ class
+ * ORB_SLAM2::ORBextractor (reference include/ORBextractor.h:45-111). Every entry point below is
+ * what a thin C++ class with that exact interface binds to (shim/ORBextractor.{h,cc} is that
+ * class); each declaration cites the reference member it replaces.
+ *
+ * Conventions: plain pointers and sizes, int status codes (0 = ORBHIP_OK, negative = error),
+ * no exceptions cross the ABI. A handle owns one HIP stream and all device workspaces; distinct
+ * handles may be used concurrently from different threads (the reference runs two extractor
+ * instances on two threads for stereo, src/Frame.cc:114-117), one handle may not.
+ */
+#ifndef ORBHIP_H
+#define ORBHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBHIP_OK 0
+#define ORBHIP_ERR_ARG (-1)          /* null pointer / bad parameter */
+#define ORBHIP_ERR_EMPTY (-2)        /* empty image: outputs untouched (src/ORBextractor.cc:1046-1047) */
+#define ORBHIP_ERR_CAPACITY (-3)     /* output or internal candidate capacity exceeded */
+#define ORBHIP_ERR_GEOMETRY (-4)     /* image shape the reference itself cannot process (division by zero at src/ORBextractor.cc:543-545) or larger than 16384 px */
+#define ORBHIP_ERR_HIP (-5)          /* a HIP runtime call failed; see orbhip_last_error() */
+#define ORBHIP_ERR_NO_DEVICE (-6)    /* no usable gfx950 device */
+#define ORBHIP_ERR_STATE (-7)        /* call not valid before an extraction */
+
+/* Blur arithmetic of cv::GaussianBlur(7x7, sigma 2) (src/ORBextractor.cc:1086), which depends on
+ * the OpenCV version the reference is linked with. */
+#define ORBHIP_BLUR_LEGACY 0         /* OpenCV 2.4 .. 3.4.1: taps {18,34,49,55,49,34,18}/256 */
+#define ORBHIP_BLUR_FIXEDPOINT 1     /* OpenCV >= 3.4.2: taps forced to sum 256, round half up */
+
+/* Same layout as cv::KeyPoint (28 bytes): the C++ class can memcpy these into its vector. */
+typedef struct orbhip_keypoint {
+    float x, y;      /* pt, level coordinates times mvScaleFactor[octave] (src/ORBextractor.cc:1095-1101) */
+    float size;      /* int(31 * mvScaleFactor[octave])                  (src/ORBextractor.cc:837,846) */
+    float angle;     /* intensity-centroid angle, degrees in [0,360)     (src/ORBextractor.cc:77-104) */
+    float response;  /* FAST corner score                                (cv::FAST, src/ORBextractor.cc:809) */
+    int octave;      /* pyramid level                                    (src/ORBextractor.cc:845) */
+    int class_id;    /* -1 */
+} orbhip_keypoint;
+
+typedef struct orbhip_params {
+    int nfeatures;        /* ORBextractor.nFeatures  */
+    float scale_factor;   /* ORBextractor.scaleFactor */
+    int nlevels;          /* ORBextractor.nLevels    */
+    int ini_th_fast;      /* ORBextractor.iniThFAST  */
+    int min_th_fast;      /* ORBextractor.minThFAST  */
+    int device;           /* HIP device ordinal */
+    int blur_variant;     /* ORBHIP_BLUR_* */
+    int max_batch;        /* frames processed per internal pass of the batch entry points (0 = default) */
+} orbhip_params;
+
+typedef struct orbhip_extractor orbhip_extractor;
+
+/* ORBextractor::ORBextractor (src/ORBextractor.cc:410-470): scale tables, per-level feature
+ * quotas, the rBRIEF pattern and the circular-patch row limits are computed here once. */
+int orbhip_create(const orbhip_params* params, orbhip_extractor** out);
+/* ORBextractor::~ORBextractor (include/ORBextractor.h:54). */
+int orbhip_destroy(orbhip_extractor* e);
+
+/* ORBextractor::operator()(image, mask, keypoints, descriptors) (src/ORBextractor.cc:1043-1105)
+ * for one 8-bit gray host image. `kp` (capacity `cap` records) and `desc` (cap x 32 bytes) are
+ * host buffers; *n receives the keypoint count. The mask argument of the reference is ignored
+ * there (include/ORBextractor.h:58) and has no counterpart here. An empty image returns
+ * ORBHIP_ERR_EMPTY and leaves the outputs untouched. */
+int orbhip_extract(orbhip_extractor* e, const uint8_t* img, int width, int height, size_t stride,
+                   orbhip_keypoint* kp, int cap, int* n, uint8_t* desc);
+
+/* The same operator() applied to `nframes` independent frames that already live in device memory
+ * (frame f starts at d_imgs + f*frame_stride, rows `row_stride` bytes apart). Outputs are device
+ * buffers: d_kp[nframes][cap], d_desc[nframes][cap][32], d_counts[nframes]. Work is enqueued on
+ * `stream` (a hipStream_t, NULL = the handle's own stream) and the call returns without waiting;
+ * frames beyond max_batch are processed in consecutive passes. This is the entry point the
+ * multi-GPU batch driver shards over (one handle per device, no collective). */
+int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int nframes, int width,
+                                int height, size_t row_stride, size_t frame_stride,
+                                orbhip_keypoint* d_kp, uint8_t* d_desc, int* d_counts, int cap,
+                                void* stream);
+
+/* Host-buffer variant of the batch call (copies in, extracts, copies out, waits). */
+int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int nframes, int width, int height,
+                         size_t row_stride, size_t frame_stride, orbhip_keypoint* kp, uint8_t* desc,
+                         int* counts, int cap);
+
+/* Waits for everything enqueued by the handle; reports a deferred capacity/geometry error. */
+int orbhip_synchronize(orbhip_extractor* e);
+
+/* Upper bound of keypoints one frame can yield (sum over levels of quota + slack of the quadtree,
+ * src/ORBextractor.cc:669-673,728-731): size `cap` with it. */
+int orbhip_max_keypoints(const orbhip_extractor* e);
+
+/* Accessors (include/ORBextractor.h:63-83). Array getters fill nlevels floats. */
+int orbhip_get_levels(const orbhip_extractor* e);                               /* GetLevels */
+float orbhip_get_scale_factor(const orbhip_extractor* e);                       /* GetScaleFactor */
+int orbhip_get_scale_factors(const orbhip_extractor* e, float* out);            /* GetScaleFactors */
+int orbhip_get_inverse_scale_factors(const orbhip_extractor* e, float* out);    /* GetInverseScaleFactors */
+int orbhip_get_scale_sigma_squares(const orbhip_extractor* e, float* out);      /* GetScaleSigmaSquares */
+int orbhip_get_inverse_scale_sigma_squares(const orbhip_extractor* e, float* out); /* GetInverseScaleSigmaSquares */
+int orbhip_get_features_per_level(const orbhip_extractor* e, int* out);         /* mnFeaturesPerLevel (include/ORBextractor.h:103) */
+int orbhip_get_umax(const orbhip_extractor* e, int* out16);                     /* umax (include/ORBextractor.h:105) */
+
+/* mvImagePyramid (include/ORBextractor.h:85; filled by ComputePyramid, src/ORBextractor.cc:1107-1132).
+ * Valid after an extraction, until the next one on this handle. `frame` indexes the frames of the
+ * last pass (0 for orbhip_extract). with_border != 0 copies the (w+38)x(h+38) buffer whose inner
+ * ROI the reference exposes. dst is a host buffer. */
+int orbhip_pyramid_info(const orbhip_extractor* e, int level, int* width, int* height);
+int orbhip_pyramid_copy(orbhip_extractor* e, int frame, int level, uint8_t* dst, size_t dst_stride,
+                        int with_border);
+
+/* Diagnostics for parity tests: the FAST corners handed to the quadtree for one level of one frame
+ * of the last pass (x, y relative to the detection window origin (16,16); response = score), in
+ * the reference's order (cell row, cell column, then raster; src/ORBextractor.cc:789-829).
+ * Returns the count (which may exceed cap) or a negative error. */
+typedef struct orbhip_candidate { int x, y, response; } orbhip_candidate;
+int orbhip_debug_candidates(orbhip_extractor* e, int frame, int level, orbhip_candidate* out, int cap);
+
+/* Per-kernel device time of the last batch call, measured with HIP events on the stream the
+ * kernels ran on. Enable first; names[i] / ms[i] are filled up to `cap` entries; returns the
+ * number of kernel classes. Enabling adds event records (and a wait in this call) only. */
+int orbhip_enable_timing(orbhip_extractor* e, int on);
+int orbhip_get_timing(orbhip_extractor* e, const char** names, float* ms, int* launches, int cap);
+
+const char* orbhip_strerror(int code);
+const char* orbhip_last_error(const orbhip_extractor* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

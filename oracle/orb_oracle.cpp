@@ -1,0 +1,743 @@
+/*
+ * orb_oracle.cpp — CPU restatement of the reference ORB extractor. TEST INFRASTRUCTURE ONLY
+ * (parity checker + timed CPU baseline; never linked into or called from the HIP library).
+ *
+ * PARITY UNPINNED: the arithmetic of resize / FAST / GaussianBlur / fastAtan2 lives in OpenCV,
+ * which the reference does not vendor and which is absent here; those routines are restated
+ * from the published OpenCV 3.x generic C++ algorithms. The reference holds no tests or golden
+ * vectors. What pins this file is the set of analytic known-answer tests in tests/.
+ *
+ * Every function cites the reference lines it follows (paths relative to the reference root).
+ * Build with -ffp-contract=off: float expressions must round exactly as written.
+ */
+#include "orb_oracle.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <list>
+#include <thread>
+#include <utility>
+#include <vector>
+
+namespace {
+
+const int kPatchSize = 31;      /* src/ORBextractor.cc:72 */
+const int kHalfPatch = 15;      /* src/ORBextractor.cc:73 */
+const int kEdge = 19;           /* src/ORBextractor.cc:74 */
+
+const int kPattern[256 * 4] = { /* src/ORBextractor.cc:150-408 */
+#include "../include/orb_pattern_31.inc"
+};
+
+/* cvRound: round half to even under the default rounding mode (OpenCV uses cvtsd2si / lrint). */
+inline int cv_round(double v) { return (int)std::lrint(v); }
+inline int cv_floor(double v) { int i = (int)v; return i - (i > v); }
+inline int cv_ceil(double v) { int i = (int)v; return i + (i < v); }
+inline short sat_short(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+inline uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+/* BORDER_REFLECT_101: ... c b | a b c ... y z | y x ... */
+inline int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) {
+        if (p < 0) p = -p;
+        else p = 2 * (len - 1) - p;
+    }
+    return p;
+}
+
+struct Plane { /* a (w+2b)x(h+2b) buffer and the inner w x h view, as src/ORBextractor.cc:1113-1115 */
+    int w = 0, h = 0, border = 0;
+    size_t step = 0;
+    std::vector<uint8_t> buf;
+    void create(int w_, int h_, int border_) {
+        w = w_; h = h_; border = border_;
+        step = (size_t)(w + 2 * border);
+        buf.assign(step * (size_t)(h + 2 * border), 0);
+    }
+    uint8_t* px() { return buf.data() + (size_t)border * step + border; }
+    const uint8_t* px() const { return buf.data() + (size_t)border * step + border; }
+};
+
+/* ---------------------------------------------------------------------------------------------
+ * cv::resize(src, dst, dsize, 0, 0, INTER_LINEAR) for CV_8UC1 (call site src/ORBextractor.cc:1120).
+ * Fixed-point bilinear: 11-bit coefficients built from float weights, horizontal pass into int32,
+ * vertical pass ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2.
+ * ------------------------------------------------------------------------------------------- */
+void resize_linear_u8(const uint8_t* src, int sw, int sh, size_t sstride,
+                      uint8_t* dst, int dw, int dh, size_t dstride) {
+    const int COEF = 2048;
+    double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
+    double scale_x = 1. / inv_x, scale_y = 1. / inv_y;
+    std::vector<int> xofs(dw), yofs(dh);
+    std::vector<short> alpha(2 * (size_t)dw), beta(2 * (size_t)dh);
+    int xmax = dw;
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx + 1 >= sw) {
+            xmax = std::min(xmax, dx);
+            if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        }
+        xofs[dx] = sx;
+        alpha[2 * dx] = sat_short(cv_round((1.f - fx) * COEF));
+        alpha[2 * dx + 1] = sat_short(cv_round(fx * COEF));
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        beta[2 * dy] = sat_short(cv_round((1.f - fy) * COEF));
+        beta[2 * dy + 1] = sat_short(cv_round(fy * COEF));
+    }
+    std::vector<int> row0(dw), row1(dw);
+    auto hpass = [&](int sy, std::vector<int>& out) {
+        sy = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
+        const uint8_t* S = src + (size_t)sy * sstride;
+        int dx = 0;
+        for (; dx < xmax; dx++) {
+            int sx = xofs[dx];
+            out[dx] = S[sx] * alpha[2 * dx] + S[sx + 1] * alpha[2 * dx + 1];
+        }
+        for (; dx < dw; dx++) out[dx] = S[xofs[dx]] * COEF;
+    };
+    int cached0 = INT32_MIN, cached1 = INT32_MIN;
+    for (int dy = 0; dy < dh; dy++) {
+        int sy0 = yofs[dy], sy1 = yofs[dy] + 1;
+        int c0 = sy0 < 0 ? 0 : (sy0 >= sh ? sh - 1 : sy0);
+        int c1 = sy1 < 0 ? 0 : (sy1 >= sh ? sh - 1 : sy1);
+        if (c0 == cached1) { std::swap(row0, row1); std::swap(cached0, cached1); }
+        if (c0 != cached0) { hpass(c0, row0); cached0 = c0; }
+        if (c1 == cached0) { row1 = row0; cached1 = c1; }
+        else if (c1 != cached1) { hpass(c1, row1); cached1 = c1; }
+        int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+        uint8_t* D = dst + (size_t)dy * dstride;
+        for (int dx = 0; dx < dw; dx++)
+            D[dx] = sat_u8((((b0 * (row0[dx] >> 4)) >> 16) + ((b1 * (row1[dx] >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+/* cv::copyMakeBorder(..., BORDER_REFLECT_101) (call sites src/ORBextractor.cc:1122,1127). */
+void border_reflect101(const uint8_t* src, int w, int h, size_t sstride,
+                       uint8_t* dst, size_t dstride, int border) {
+    for (int y = -border; y < h + border; y++) {
+        const uint8_t* S = src + (size_t)reflect101(y, h) * sstride;
+        uint8_t* D = dst + (size_t)(y + border) * dstride;
+        for (int x = -border; x < w + border; x++) D[x + border] = S[reflect101(x, w)];
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * cv::FAST(img, keypoints, threshold, true) — FAST-9 on the 16-pixel Bresenham circle of radius 3
+ * with 3x3 non-maximum suppression on the corner score (call sites src/ORBextractor.cc:809,814).
+ * Pixels closer than 3 to the border of `img` are never corners and score 0 in the NMS.
+ * Output is in raster order; response = corner score.
+ * ------------------------------------------------------------------------------------------- */
+const int kCircle[16][2] = {{0, 3}, {1, 3}, {2, 2}, {3, 1}, {3, 0}, {3, -1}, {2, -2}, {1, -3},
+                            {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+
+/* Corner score: the largest t' such that the pixel is still a FAST-9 corner at threshold t',
+ * floored by the threshold it was detected with (irrelevant for true corners). */
+inline int corner_score(const uint8_t* p, const int* ofs, int threshold) {
+    int d[25];
+    int v = p[0];
+    for (int k = 0; k < 25; k++) d[k] = v - p[ofs[k % 16]];
+    int a0 = threshold;
+    for (int k = 0; k < 16; k++) { /* centre brighter than a whole 9-arc */
+        int a = d[k];
+        for (int j = 1; j < 9; j++) a = std::min(a, d[k + j]);
+        a0 = std::max(a0, a);
+    }
+    int b0 = -a0;
+    for (int k = 0; k < 16; k++) { /* centre darker than a whole 9-arc */
+        int b = d[k];
+        for (int j = 1; j < 9; j++) b = std::max(b, d[k + j]);
+        b0 = std::min(b0, b);
+    }
+    return -b0 - 1;
+}
+
+int fast9(const uint8_t* img, int w, int h, size_t stride, int threshold,
+          std::vector<orbo_candidate>& out) {
+    out.clear();
+    if (w < 7 || h < 7) return 0;
+    int ofs[16];
+    for (int k = 0; k < 16; k++) ofs[k] = kCircle[k][0] + kCircle[k][1] * (int)stride;
+    threshold = std::min(std::max(threshold, 0), 255);
+    std::vector<int> score((size_t)w * h, 0);
+    for (int y = 3; y < h - 3; y++) {
+        const uint8_t* row = img + (size_t)y * stride;
+        for (int x = 3; x < w - 3; x++) {
+            const uint8_t* p = row + x;
+            int v = p[0];
+            int lo = v - threshold, hi = v + threshold;
+            /* any 9-arc contains one pixel of every opposite pair: quick rejection */
+            int cls = 3;
+            for (int k = 0; k < 8 && cls; k++) {
+                int a = p[ofs[k]], b = p[ofs[k + 8]];
+                int c = (a < lo ? 1 : 0) | (a > hi ? 2 : 0) | (b < lo ? 1 : 0) | (b > hi ? 2 : 0);
+                cls &= c;
+            }
+            if (!cls) continue;
+            bool corner = false;
+            if (cls & 1) {
+                int run = 0;
+                for (int k = 0; k < 25; k++) {
+                    if (p[ofs[k % 16]] < lo) { if (++run > 8) { corner = true; break; } }
+                    else run = 0;
+                }
+            }
+            if (!corner && (cls & 2)) {
+                int run = 0;
+                for (int k = 0; k < 25; k++) {
+                    if (p[ofs[k % 16]] > hi) { if (++run > 8) { corner = true; break; } }
+                    else run = 0;
+                }
+            }
+            if (corner) score[(size_t)y * w + x] = corner_score(p, ofs, threshold);
+        }
+    }
+    for (int y = 3; y < h - 3; y++) {
+        const int* s = &score[(size_t)y * w];
+        for (int x = 3; x < w - 3; x++) {
+            int sc = s[x];
+            if (!sc) continue;
+            if (sc > s[x - 1] && sc > s[x + 1] && sc > s[x - w - 1] && sc > s[x - w] && sc > s[x - w + 1] &&
+                sc > s[x + w - 1] && sc > s[x + w] && sc > s[x + w + 1])
+                out.push_back(orbo_candidate{x, y, sc});
+        }
+    }
+    return (int)out.size();
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * cv::GaussianBlur(img, img, Size(7,7), 2, 2, BORDER_REFLECT_101) for CV_8UC1
+ * (call site src/ORBextractor.cc:1085-1086).
+ *
+ * LEGACY (OpenCV 2.4 .. 3.4.1, what "tested with 2.4.11 and 3.2" in README.md:68 means):
+ *   float kernel exp(-x^2/8)/sum -> *256 -> round = {18,34,49,55,49,34,18} (sum 257, not
+ *   renormalised); exact int32 row pass; column pass scaled by 2^-16. The x86 column kernel
+ *   works in float and converts with round-half-to-even for the first (w & ~3) pixels of a row;
+ *   the scalar tail uses (v + 32768) >> 16 (round half up). Both are reproduced.
+ * FIXEDPOINT (OpenCV >= 3.4.2): 8.8 fixed-point kernel that sums to exactly 256, 16.16
+ *   accumulation, round half up. The tap values of that path are restated, not verified.
+ * ------------------------------------------------------------------------------------------- */
+void gaussian_taps(int variant, int taps[4]) { /* taps[0] = centre */
+    double k[7], sum = 0;
+    for (int i = 0; i < 7; i++) { double x = i - 3; float t = (float)std::exp(-0.5 / 4.0 * x * x); k[i] = t; sum += t; }
+    double scale = 1. / sum;
+    float kf[7];
+    for (int i = 0; i < 7; i++) kf[i] = (float)(k[i] * scale);
+    int q[7], qs = 0;
+    for (int i = 0; i < 7; i++) { q[i] = cv_round(kf[i] * 256.f); qs += q[i]; }
+    if (variant == ORBO_BLUR_FIXEDPOINT) q[3] -= (qs - 256); /* fold the rounding excess into the centre tap */
+    taps[0] = q[3]; taps[1] = q[2]; taps[2] = q[1]; taps[3] = q[0];
+}
+
+void gaussian_blur7(const uint8_t* src, int w, int h, size_t sstride,
+                    uint8_t* dst, size_t dstride, int variant) {
+    int t[4];
+    gaussian_taps(variant, t);
+    std::vector<int> rows((size_t)w * h);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* S = src + (size_t)y * sstride;
+        int* R = &rows[(size_t)y * w];
+        for (int x = 0; x < w; x++) {
+            int acc = t[0] * S[x];
+            for (int k = 1; k <= 3; k++) acc += t[k] * (S[reflect101(x - k, w)] + S[reflect101(x + k, w)]);
+            R[x] = acc;
+        }
+    }
+    const int wv = w & ~3;
+    for (int y = 0; y < h; y++) {
+        uint8_t* D = dst + (size_t)y * dstride;
+        const int* R0 = &rows[(size_t)y * w];
+        for (int x = 0; x < w; x++) {
+            int acc = t[0] * R0[x];
+            for (int k = 1; k <= 3; k++)
+                acc += t[k] * (rows[(size_t)reflect101(y - k, h) * w + x] + rows[(size_t)reflect101(y + k, h) * w + x]);
+            int q = acc >> 16, r = acc & 0xFFFF;
+            if (r > 32768) q++;
+            else if (r == 32768) {
+                if (variant == ORBO_BLUR_LEGACY && x < wv) q += (q & 1); /* cvtps2dq: ties to even */
+                else q++;
+            }
+            D[x] = sat_u8(q);
+        }
+    }
+}
+
+/* cv::fastAtan2 (call site src/ORBextractor.cc:103): 7th-order odd polynomial, degrees in [0,360). */
+float fast_atan2(float y, float x) {
+    const float s = (float)(180 / 3.141592653589793238462643383279502884);
+    const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s;
+    const float p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
+    const float eps = (float)2.2204460492503131e-16;
+    float ax = std::fabs(x), ay = std::fabs(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Quadtree ("OctTree") distribution — ExtractorNode::DivideNode and ORBextractor::DistributeOctTree
+ * (src/ORBextractor.cc:481-537, 539-763), kept as a std::list walk like the reference.
+ * The reference orders equal-sized nodes in its final expansion rounds by heap address
+ * (std::pair<int, ExtractorNode*> sort, :591,:684). ORBO_TIE_CREATION_ORDER replaces the address by
+ * the node's creation sequence number (what a monotonic allocator would give);
+ * ORBO_TIE_HEAP_ADDRESS keeps the literal, allocator-dependent comparison.
+ * ------------------------------------------------------------------------------------------- */
+struct Key { float x, y, response; };
+
+struct Node {
+    std::vector<Key> keys;
+    int ulx = 0, uly = 0, urx = 0, bry = 0; /* UL=(ulx,uly) UR=(urx,uly) BL=(ulx,bry) BR=(urx,bry) */
+    std::list<Node>::iterator lit;
+    bool no_more = false;
+    long seq = 0;
+};
+
+void divide_node(const Node& p, Node& n1, Node& n2, Node& n3, Node& n4) { /* :481-537 */
+    const int halfX = (int)std::ceil(static_cast<float>(p.urx - p.ulx) / 2);
+    const int halfY = (int)std::ceil(static_cast<float>(p.bry - p.uly) / 2);
+    const int mx = p.ulx + halfX, my = p.uly + halfY;
+    n1.ulx = p.ulx; n1.urx = mx;    n1.uly = p.uly; n1.bry = my;
+    n2.ulx = mx;    n2.urx = p.urx; n2.uly = p.uly; n2.bry = my;
+    n3.ulx = p.ulx; n3.urx = mx;    n3.uly = my;    n3.bry = p.bry;
+    n4.ulx = mx;    n4.urx = p.urx; n4.uly = my;    n4.bry = p.bry;
+    for (const Key& k : p.keys) {
+        if (k.x < (float)mx) {
+            if (k.y < (float)my) n1.keys.push_back(k); else n3.keys.push_back(k);
+        } else if (k.y < (float)my) n2.keys.push_back(k);
+        else n4.keys.push_back(k);
+    }
+    n1.no_more = n1.keys.size() == 1;
+    n2.no_more = n2.keys.size() == 1;
+    n3.no_more = n3.keys.size() == 1;
+    n4.no_more = n4.keys.size() == 1;
+}
+
+typedef std::pair<int, Node*> SizeNode;
+
+struct TieLess {
+    int mode;
+    bool operator()(const SizeNode& a, const SizeNode& b) const {
+        if (a.first != b.first) return a.first < b.first;
+        if (mode == ORBO_TIE_HEAP_ADDRESS) return std::less<Node*>()(a.second, b.second);
+        return a.second->seq < b.second->seq;
+    }
+};
+
+/* returns -3 when the reference would divide by zero (nIni == 0) */
+int distribute_octtree(const std::vector<Key>& in, int minX, int maxX, int minY, int maxY, int N,
+                       int tie_mode, std::vector<Key>& result) {
+    result.clear();
+    const int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY)); /* :543 */
+    if (nIni < 1) return -3;
+    const float hX = static_cast<float>(maxX - minX) / nIni;                           /* :545 */
+    std::list<Node> nodes;
+    std::vector<Node*> ini(nIni);
+    long seq = 0;
+    for (int i = 0; i < nIni; i++) {                                                   /* :552-563 */
+        Node n;
+        n.ulx = (int)(hX * static_cast<float>(i));
+        n.urx = (int)(hX * static_cast<float>(i + 1));
+        n.uly = 0;
+        n.bry = maxY - minY;
+        n.seq = seq++;
+        nodes.push_back(n);
+        ini[i] = &nodes.back();
+    }
+    for (const Key& k : in) {                                                          /* :566-570 */
+        size_t idx = (size_t)(k.x / hX);
+        if (idx >= ini.size()) return -3;
+        ini[idx]->keys.push_back(k);
+    }
+    for (auto it = nodes.begin(); it != nodes.end();) {                                /* :574-585 */
+        if (it->keys.size() == 1) { it->no_more = true; ++it; }
+        else if (it->keys.empty()) it = nodes.erase(it);
+        else ++it;
+    }
+    bool finish = false;
+    std::vector<SizeNode> pending;
+    TieLess less{tie_mode};
+    auto push_child = [&](Node& c, std::vector<SizeNode>& rec, int* to_expand) {
+        if (c.keys.empty()) return;
+        c.seq = seq++;
+        nodes.push_front(c);
+        if (c.keys.size() > 1) {
+            if (to_expand) ++*to_expand;
+            rec.push_back(std::make_pair((int)c.keys.size(), &nodes.front()));
+            nodes.front().lit = nodes.begin();
+        }
+    };
+    while (!finish) {                                                                  /* :594-739 */
+        int prev = (int)nodes.size();
+        int to_expand = 0;
+        pending.clear();
+        for (auto it = nodes.begin(); it != nodes.end();) {                            /* :606-665 */
+            if (it->no_more) { ++it; continue; }
+            Node n1, n2, n3, n4;
+            divide_node(*it, n1, n2, n3, n4);
+            push_child(n1, pending, &to_expand);
+            push_child(n2, pending, &to_expand);
+            push_child(n3, pending, &to_expand);
+            push_child(n4, pending, &to_expand);
+            it = nodes.erase(it);
+        }
+        if ((int)nodes.size() >= N || (int)nodes.size() == prev) {                     /* :669-672 */
+            finish = true;
+        } else if ((int)nodes.size() + to_expand * 3 > N) {                            /* :673-738 */
+            while (!finish) {
+                prev = (int)nodes.size();
+                std::vector<SizeNode> todo = pending;
+                pending.clear();
+                std::sort(todo.begin(), todo.end(), less);                            /* :684 */
+                for (int j = (int)todo.size() - 1; j >= 0; j--) {
+                    Node n1, n2, n3, n4;
+                    divide_node(*todo[j].second, n1, n2, n3, n4);
+                    push_child(n1, pending, nullptr);
+                    push_child(n2, pending, nullptr);
+                    push_child(n3, pending, nullptr);
+                    push_child(n4, pending, nullptr);
+                    nodes.erase(todo[j].second->lit);
+                    if ((int)nodes.size() >= N) break;
+                }
+                if ((int)nodes.size() >= N || (int)nodes.size() == prev) finish = true;
+            }
+        }
+    }
+    result.reserve(nodes.size());
+    for (const Node& n : nodes) {                                                      /* :744-760 */
+        const Key* best = &n.keys[0];
+        for (size_t k = 1; k < n.keys.size(); k++)
+            if (n.keys[k].response > best->response) best = &n.keys[k];
+        result.push_back(*best);
+    }
+    return 0;
+}
+
+} // namespace
+
+/* ============================================================================================ */
+
+struct orbo_extractor {
+    int nfeatures, nlevels, ini_th, min_th, blur_variant, tie_mode, fma_mode;
+    double scale_factor; /* float argument widened to double, include/ORBextractor.h:98 */
+    std::vector<float> sf, inv_sf, sigma2, inv_sigma2;
+    std::vector<int> per_level, umax;
+    /* state of the last extract */
+    std::vector<Plane> pyr, blurred;
+    std::vector<std::vector<orbo_candidate>> cand;
+    std::vector<std::vector<orbo_keypoint>> level_kp;
+};
+
+namespace {
+
+/* IC_Angle (src/ORBextractor.cc:77-104) */
+float ic_angle(const Plane& im, float px, float py, const std::vector<int>& umax) {
+    int m_01 = 0, m_10 = 0;
+    const int step = (int)im.step;
+    const uint8_t* c = im.px() + (size_t)cv_round(py) * im.step + cv_round(px);
+    for (int u = -kHalfPatch; u <= kHalfPatch; ++u) m_10 += u * c[u];
+    for (int v = 1; v <= kHalfPatch; ++v) {
+        int v_sum = 0, d = umax[v];
+        for (int u = -d; u <= d; ++u) {
+            int vp = c[u + v * step], vm = c[u - v * step];
+            v_sum += (vp - vm);
+            m_10 += u * (vp + vm);
+        }
+        m_01 += v * v_sum;
+    }
+    return fast_atan2((float)m_01, (float)m_10);
+}
+
+/* computeOrbDescriptor (src/ORBextractor.cc:107-147) */
+void orb_descriptor(const orbo_keypoint& kp, const Plane& im, int fma_mode, uint8_t* desc) {
+    const float factorPI = (float)(3.141592653589793238462643383279502884 / 180.f);
+    float angle = kp.angle * factorPI;
+    float a = cosf(angle), b = sinf(angle);
+    const uint8_t* c = im.px() + (size_t)cv_round(kp.y) * im.step + cv_round(kp.x);
+    const int step = (int)im.step;
+    auto val = [&](int idx) -> int {
+        float x = (float)kPattern[2 * idx], y = (float)kPattern[2 * idx + 1];
+        float ry, rx;
+        if (fma_mode == ORBO_FMA_ON) { ry = fmaf(x, b, y * a); rx = fmaf(x, a, -(y * b)); }
+        else { ry = x * b + y * a; rx = x * a - y * b; }
+        return c[cv_round(ry) * step + cv_round(rx)];
+    };
+    for (int i = 0; i < 32; i++) {
+        int v = 0;
+        for (int j = 0; j < 8; j++) {
+            int t0 = val(16 * i + 2 * j), t1 = val(16 * i + 2 * j + 1);
+            v |= (t0 < t1) << j;
+        }
+        desc[i] = (uint8_t)v;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+orbo_extractor* orbo_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
+                            int min_th_fast, int blur_variant, int tie_mode, int fma_mode) {
+    if (nfeatures < 1 || nlevels < 1 || nlevels > 32 || !(scale_factor > 1.0f)) return nullptr;
+    orbo_extractor* e = new orbo_extractor;
+    e->nfeatures = nfeatures; e->nlevels = nlevels; e->ini_th = ini_th_fast; e->min_th = min_th_fast;
+    e->blur_variant = blur_variant; e->tie_mode = tie_mode; e->fma_mode = fma_mode;
+    e->scale_factor = scale_factor;
+    /* src/ORBextractor.cc:415-431 */
+    e->sf.resize(nlevels); e->sigma2.resize(nlevels); e->inv_sf.resize(nlevels); e->inv_sigma2.resize(nlevels);
+    e->sf[0] = 1.0f; e->sigma2[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) {
+        e->sf[i] = (float)(e->sf[i - 1] * e->scale_factor);
+        e->sigma2[i] = e->sf[i] * e->sf[i];
+    }
+    for (int i = 0; i < nlevels; i++) {
+        e->inv_sf[i] = 1.0f / e->sf[i];
+        e->inv_sigma2[i] = 1.0f / e->sigma2[i];
+    }
+    /* src/ORBextractor.cc:435-446 */
+    e->per_level.resize(nlevels);
+    float factor = (float)(1.0f / e->scale_factor);
+    float desired = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; l++) {
+        e->per_level[l] = cv_round(desired);
+        sum += e->per_level[l];
+        desired *= factor;
+    }
+    e->per_level[nlevels - 1] = std::max(nfeatures - sum, 0);
+    /* src/ORBextractor.cc:454-469 */
+    e->umax.assign(kHalfPatch + 2, 0);
+    int v, v0, vmax = cv_floor(kHalfPatch * std::sqrt(2.f) / 2 + 1);
+    int vmin = cv_ceil(kHalfPatch * std::sqrt(2.f) / 2);
+    const double hp2 = kHalfPatch * kHalfPatch;
+    for (v = 0; v <= vmax; ++v) e->umax[v] = cv_round(std::sqrt(hp2 - v * v));
+    for (v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+        while (e->umax[v0] == e->umax[v0 + 1]) ++v0;
+        e->umax[v] = v0;
+        ++v0;
+    }
+    e->umax.resize(kHalfPatch + 1);
+    return e;
+}
+
+void orbo_destroy(orbo_extractor* e) { delete e; }
+
+int orbo_extract(orbo_extractor* e, const uint8_t* img, int w, int h, size_t stride,
+                 orbo_keypoint* kp_out, int cap, int* n_out, uint8_t* desc_out) {
+    if (n_out) *n_out = 0;
+    if (!img || w <= 0 || h <= 0) return -1;                                   /* :1046-1047 */
+    const int nl = e->nlevels;
+    /* ComputePyramid (:1107-1132) */
+    e->pyr.assign(nl, Plane());
+    for (int l = 0; l < nl; l++) {
+        float scale = e->inv_sf[l];
+        int lw = cv_round((float)w * scale), lh = cv_round((float)h * scale);
+        if (lw < 1 || lh < 1) return -3;
+        Plane& P = e->pyr[l];
+        P.create(lw, lh, kEdge);
+        if (l != 0) {
+            const Plane& S = e->pyr[l - 1];
+            std::vector<uint8_t> tmp((size_t)lw * lh);
+            resize_linear_u8(S.px(), S.w, S.h, S.step, tmp.data(), lw, lh, (size_t)lw);
+            border_reflect101(tmp.data(), lw, lh, (size_t)lw, P.buf.data(), P.step, kEdge);
+        } else {
+            border_reflect101(img, w, h, stride, P.buf.data(), P.step, kEdge);
+        }
+    }
+    /* ComputeKeyPointsOctTree (:765-853) */
+    e->cand.assign(nl, {});
+    e->level_kp.assign(nl, {});
+    const float W = 30;
+    std::vector<orbo_candidate> cell;
+    for (int l = 0; l < nl; l++) {
+        const Plane& P = e->pyr[l];
+        const int minBX = kEdge - 3, minBY = minBX;
+        const int maxBX = P.w - kEdge + 3, maxBY = P.h - kEdge + 3;
+        const float width = (float)(maxBX - minBX), height = (float)(maxBY - minBY);
+        const int nCols = (int)(width / W), nRows = (int)(height / W);
+        if (nCols < 1 || nRows < 1) continue; /* reference: no cell is visited, level stays empty */
+        const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+        std::vector<orbo_candidate>& all = e->cand[l];
+        for (int i = 0; i < nRows; i++) {
+            const float iniY = (float)(minBY + i * hCell);
+            float maxY = iniY + hCell + 6;
+            if (iniY >= maxBY - 3) continue;
+            if (maxY > maxBY) maxY = (float)maxBY;
+            for (int j = 0; j < nCols; j++) {
+                const float iniX = (float)(minBX + j * wCell);
+                float maxX = iniX + wCell + 6;
+                if (iniX >= maxBX - 6) continue;
+                if (maxX > maxBX) maxX = (float)maxBX;
+                const int x0 = (int)iniX, y0 = (int)iniY, cw = (int)maxX - x0, ch = (int)maxY - y0;
+                const uint8_t* sub = P.px() + (size_t)y0 * P.step + x0;
+                fast9(sub, cw, ch, P.step, e->ini_th, cell);
+                if (cell.empty()) fast9(sub, cw, ch, P.step, e->min_th, cell);
+                for (const orbo_candidate& c : cell)
+                    all.push_back(orbo_candidate{c.x + j * wCell, c.y + i * hCell, c.response});
+            }
+        }
+        std::vector<Key> keys(all.size()), kept;
+        for (size_t k = 0; k < all.size(); k++) keys[k] = Key{(float)all[k].x, (float)all[k].y, (float)all[k].response};
+        int rc = distribute_octtree(keys, minBX, maxBX, minBY, maxBY, e->per_level[l], e->tie_mode, kept);
+        if (rc) return rc;
+        const int scaledPatch = (int)(kPatchSize * e->sf[l]);                   /* :837 */
+        std::vector<orbo_keypoint>& out = e->level_kp[l];
+        for (const Key& k : kept) {
+            orbo_keypoint q;
+            q.x = k.x + minBX; q.y = k.y + minBY;
+            q.size = (float)scaledPatch; q.angle = -1.f; q.response = k.response;
+            q.octave = l; q.class_id = -1;
+            out.push_back(q);
+        }
+    }
+    for (int l = 0; l < nl; l++)                                                /* :851-852 */
+        for (orbo_keypoint& q : e->level_kp[l]) q.angle = ic_angle(e->pyr[l], q.x, q.y, e->umax);
+    /* operator() tail (:1059-1104) */
+    int total = 0;
+    for (int l = 0; l < nl; l++) total += (int)e->level_kp[l].size();
+    if (n_out) *n_out = total;
+    e->blurred.assign(nl, Plane());
+    if ((kp_out || desc_out) && total > cap) return -2;
+    int offset = 0;
+    for (int l = 0; l < nl; l++) {
+        std::vector<orbo_keypoint>& kps = e->level_kp[l];
+        if (kps.empty()) continue;
+        const Plane& P = e->pyr[l];
+        Plane& B = e->blurred[l];
+        B.create(P.w, P.h, 0);
+        gaussian_blur7(P.px(), P.w, P.h, P.step, B.px(), B.step, e->blur_variant);
+        for (size_t k = 0; k < kps.size(); k++) {
+            if (desc_out) orb_descriptor(kps[k], B, e->fma_mode, desc_out + (size_t)(offset + k) * 32);
+            if (kp_out) {
+                orbo_keypoint q = kps[k];
+                if (l != 0) { float s = e->sf[l]; q.x *= s; q.y *= s; }
+                kp_out[offset + k] = q;
+            }
+        }
+        offset += (int)kps.size();
+    }
+    return 0;
+}
+
+int orbo_levels(const orbo_extractor* e) { return e->nlevels; }
+float orbo_scale_factor(const orbo_extractor* e) { return (float)e->scale_factor; }
+void orbo_table(const orbo_extractor* e, int which, float* out) {
+    const std::vector<float>& t = which == 0 ? e->sf : which == 1 ? e->inv_sf : which == 2 ? e->sigma2 : e->inv_sigma2;
+    std::memcpy(out, t.data(), t.size() * sizeof(float));
+}
+void orbo_features_per_level(const orbo_extractor* e, int* out) { std::memcpy(out, e->per_level.data(), e->per_level.size() * sizeof(int)); }
+void orbo_umax(const orbo_extractor* e, int* out16) { std::memcpy(out16, e->umax.data(), 16 * sizeof(int)); }
+
+int orbo_level_size(const orbo_extractor* e, int level, int* w, int* h) {
+    if (level < 0 || level >= (int)e->pyr.size()) return -1;
+    *w = e->pyr[level].w; *h = e->pyr[level].h;
+    return 0;
+}
+int orbo_level_copy(const orbo_extractor* e, int level, uint8_t* dst, size_t dst_stride, int with_border) {
+    if (level < 0 || level >= (int)e->pyr.size()) return -1;
+    const Plane& P = e->pyr[level];
+    if (with_border) {
+        for (int y = 0; y < P.h + 2 * kEdge; y++) std::memcpy(dst + (size_t)y * dst_stride, P.buf.data() + (size_t)y * P.step, P.step);
+    } else {
+        for (int y = 0; y < P.h; y++) std::memcpy(dst + (size_t)y * dst_stride, P.px() + (size_t)y * P.step, P.w);
+    }
+    return 0;
+}
+int orbo_blurred_copy(const orbo_extractor* e, int level, uint8_t* dst, size_t dst_stride) {
+    if (level < 0 || level >= (int)e->blurred.size()) return -1;
+    const Plane& B = e->blurred[level];
+    if (B.w == 0) return 0;
+    for (int y = 0; y < B.h; y++) std::memcpy(dst + (size_t)y * dst_stride, B.px() + (size_t)y * B.step, B.w);
+    return 1;
+}
+int orbo_level_candidates(const orbo_extractor* e, int level, orbo_candidate* out, int cap) {
+    if (level < 0 || level >= (int)e->cand.size()) return -1;
+    int n = (int)e->cand[level].size();
+    if (out) std::memcpy(out, e->cand[level].data(), sizeof(orbo_candidate) * (size_t)std::min(n, cap));
+    return n;
+}
+int orbo_level_keypoints(const orbo_extractor* e, int level, orbo_keypoint* out, int cap) {
+    if (level < 0 || level >= (int)e->level_kp.size()) return -1;
+    int n = (int)e->level_kp[level].size();
+    if (out) std::memcpy(out, e->level_kp[level].data(), sizeof(orbo_keypoint) * (size_t)std::min(n, cap));
+    return n;
+}
+
+void orbo_resize_linear_u8(const uint8_t* src, int sw, int sh, size_t sstride,
+                           uint8_t* dst, int dw, int dh, size_t dstride) {
+    resize_linear_u8(src, sw, sh, sstride, dst, dw, dh, dstride);
+}
+void orbo_border_reflect101(const uint8_t* src, int w, int h, size_t sstride,
+                            uint8_t* dst, size_t dstride, int border) {
+    border_reflect101(src, w, h, sstride, dst, dstride, border);
+}
+int orbo_fast9(const uint8_t* img, int w, int h, size_t stride, int threshold, orbo_candidate* out, int cap) {
+    std::vector<orbo_candidate> v;
+    fast9(img, w, h, stride, threshold, v);
+    if (out) std::memcpy(out, v.data(), sizeof(orbo_candidate) * std::min(v.size(), (size_t)std::max(cap, 0)));
+    return (int)v.size();
+}
+void orbo_gaussian_blur7(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride, int blur_variant) {
+    gaussian_blur7(src, w, h, sstride, dst, dstride, blur_variant);
+}
+float orbo_fast_atan2(float y, float x) { return fast_atan2(y, x); }
+
+int orbo_distribute(const orbo_candidate* cand, int ncand, int min_x, int max_x, int min_y, int max_y,
+                    int n_wanted, int tie_mode, orbo_candidate* out, int cap) {
+    std::vector<Key> keys(ncand), kept;
+    for (int i = 0; i < ncand; i++) keys[i] = Key{(float)cand[i].x, (float)cand[i].y, (float)cand[i].response};
+    int rc = distribute_octtree(keys, min_x, max_x, min_y, max_y, n_wanted, tie_mode, kept);
+    if (rc) return rc;
+    for (size_t i = 0; i < kept.size() && (int)i < cap; i++)
+        out[i] = orbo_candidate{(int)kept[i].x, (int)kept[i].y, (int)kept[i].response};
+    return (int)kept.size();
+}
+
+double orbo_extract_batch_mt(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
+                             int min_th_fast, int blur_variant, const uint8_t* imgs, int nframes,
+                             int w, int h, size_t row_stride, size_t frame_stride, int nthreads,
+                             int* counts) {
+    if (nthreads < 1) nthreads = 1;
+    const int cap = nfeatures + 4 * nlevels + 64;
+    std::vector<orbo_extractor*> ex(nthreads);
+    for (auto& p : ex) p = orbo_create(nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast, blur_variant,
+                                       ORBO_TIE_CREATION_ORDER, ORBO_FMA_OFF);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; t++) {
+        pool.emplace_back([&, t]() {
+            std::vector<orbo_keypoint> kp(cap);
+            std::vector<uint8_t> desc((size_t)cap * 32);
+            for (int f = t; f < nframes; f += nthreads) {
+                int n = 0;
+                orbo_extract(ex[t], imgs + (size_t)f * frame_stride, w, h, row_stride, kp.data(), cap, &n, desc.data());
+                if (counts) counts[f] = n;
+            }
+        });
+    }
+    for (auto& th : pool) th.join();
+    double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (auto p : ex) orbo_destroy(p);
+    return dt;
+}
+
+} // extern "C"

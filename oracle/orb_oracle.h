@@ -1,0 +1,96 @@
+/*
+ * orb_oracle — CPU restatement of the reference ORB extractor. TEST INFRASTRUCTURE ONLY.
+ *
+ * This library is the parity checker and the timed CPU baseline. It is never part of the
+ * shipped extraction path: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load it.
+ *
+ * It restates ORB_SLAM2::ORBextractor (reference src/ORBextractor.cc, include/ORBextractor.h)
+ * and the OpenCV 3.x generic C++ routines that class calls (resize INTER_LINEAR 8U,
+ * copyMakeBorder REFLECT_101, FAST 9_16 + NMS, GaussianBlur 7x7 sigma 2, fastAtan2, cvRound).
+ * OpenCV is not vendored by the reference and is absent from the build image, and the
+ * reference has no tests or golden vectors, so this restatement is PARITY UNPINNED against a
+ * real OpenCV build; it is pinned only by the analytic known-answer tests under tests/.
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same 28-byte record as cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id). */
+typedef struct orbo_keypoint {
+    float x, y, size, angle, response;
+    int octave, class_id;
+} orbo_keypoint;
+
+typedef struct orbo_candidate { /* one FAST corner handed to the quadtree, window-relative coords */
+    int x, y, response;
+} orbo_candidate;
+
+typedef struct orbo_extractor orbo_extractor;
+
+enum { ORBO_BLUR_LEGACY = 0, ORBO_BLUR_FIXEDPOINT = 1 };
+enum { ORBO_TIE_CREATION_ORDER = 0, ORBO_TIE_HEAP_ADDRESS = 1 };
+enum { ORBO_FMA_OFF = 0, ORBO_FMA_ON = 1 };
+
+/* ORBextractor::ORBextractor (src/ORBextractor.cc:410-470). Returns NULL on bad arguments. */
+orbo_extractor* orbo_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
+                            int min_th_fast, int blur_variant, int tie_mode, int fma_mode);
+void orbo_destroy(orbo_extractor* e);
+
+/* ORBextractor::operator() (src/ORBextractor.cc:1043-1105). kp/desc may be NULL to only count.
+ * Returns 0, or a negative code: -1 empty image, -2 capacity too small, -3 unsupported geometry
+ * (the reference divides by zero for these). *n receives the keypoint count. */
+int orbo_extract(orbo_extractor* e, const uint8_t* img, int w, int h, size_t stride,
+                 orbo_keypoint* kp, int cap, int* n, uint8_t* desc);
+
+/* Tables (accessors at include/ORBextractor.h:63-83 and the protected vectors). */
+int orbo_levels(const orbo_extractor* e);
+float orbo_scale_factor(const orbo_extractor* e);
+/* which: 0 mvScaleFactor, 1 mvInvScaleFactor, 2 mvLevelSigma2, 3 mvInvLevelSigma2 */
+void orbo_table(const orbo_extractor* e, int which, float* out);
+void orbo_features_per_level(const orbo_extractor* e, int* out);
+void orbo_umax(const orbo_extractor* e, int* out16);
+
+/* State of the last orbo_extract call on this instance. */
+int orbo_level_size(const orbo_extractor* e, int level, int* w, int* h);
+/* Copies level pixels; with_border != 0 copies the (w+38)x(h+38) bordered buffer. */
+int orbo_level_copy(const orbo_extractor* e, int level, uint8_t* dst, size_t dst_stride, int with_border);
+/* Blurred level (the image the descriptors were sampled from); 0 if the level had no keypoints. */
+int orbo_blurred_copy(const orbo_extractor* e, int level, uint8_t* dst, size_t dst_stride);
+/* Candidates handed to DistributeOctTree for a level, in the reference's order. Returns count. */
+int orbo_level_candidates(const orbo_extractor* e, int level, orbo_candidate* out, int cap);
+/* Keypoints of one level after DistributeOctTree, level coordinates. Returns count. */
+int orbo_level_keypoints(const orbo_extractor* e, int level, orbo_keypoint* out, int cap);
+
+/* Stand-alone stages, for known-answer tests. */
+void orbo_resize_linear_u8(const uint8_t* src, int sw, int sh, size_t sstride,
+                           uint8_t* dst, int dw, int dh, size_t dstride);
+void orbo_border_reflect101(const uint8_t* src, int w, int h, size_t sstride,
+                            uint8_t* dst, size_t dstride, int border);
+/* cv::FAST(img, kps, threshold, nonmax=true), TYPE_9_16. Returns count (may exceed cap). */
+int orbo_fast9(const uint8_t* img, int w, int h, size_t stride, int threshold,
+               orbo_candidate* out, int cap);
+void orbo_gaussian_blur7(const uint8_t* src, int w, int h, size_t sstride,
+                         uint8_t* dst, size_t dstride, int blur_variant);
+float orbo_fast_atan2(float y, float x);
+/* DistributeOctTree on a hand-built candidate set (coords relative to minX/minY). Returns count. */
+int orbo_distribute(const orbo_candidate* cand, int ncand, int min_x, int max_x, int min_y, int max_y,
+                    int n_wanted, int tie_mode, orbo_candidate* out, int cap);
+
+/* CPU baseline: nthreads workers, one extractor instance each, frames dealt round-robin.
+ * counts[nframes] receives per-frame keypoint counts; returns elapsed seconds (steady clock). */
+double orbo_extract_batch_mt(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
+                             int min_th_fast, int blur_variant, const uint8_t* imgs, int nframes,
+                             int w, int h, size_t row_stride, size_t frame_stride, int nthreads,
+                             int* counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,207 @@
+"""ctypes binding of the CPU oracle (liborb_oracle.so). TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the HIP extraction path never does.
+"""
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB = _HERE / "liborb_oracle.so"
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+CAND_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("response", "<i4")])
+
+BLUR_LEGACY, BLUR_FIXEDPOINT = 0, 1
+TIE_CREATION_ORDER, TIE_HEAP_ADDRESS = 0, 1
+FMA_OFF, FMA_ON = 0, 1
+
+
+def build(force=False):
+    """Compile the oracle with g++ (seconds). No-op when the library is newer than its sources."""
+    srcs = [_HERE / "orb_oracle.cpp", _HERE / "orb_oracle.h", _HERE.parent / "include" / "orb_pattern_31.inc"]
+    if not force and _LIB.exists() and all(_LIB.stat().st_mtime >= s.stat().st_mtime for s in srcs):
+        return _LIB
+    subprocess.check_call(["make", "-C", str(_HERE), "-B", "liborb_oracle.so"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not _LIB.exists():
+            build()
+        L = C.CDLL(str(_LIB))
+        u8p, f32p, i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_int)
+        L.orbo_create.restype = C.c_void_p
+        L.orbo_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orbo_destroy.argtypes = [C.c_void_p]
+        L.orbo_extract.restype = C.c_int
+        L.orbo_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, i32p, C.c_void_p]
+        L.orbo_levels.argtypes = [C.c_void_p]
+        L.orbo_scale_factor.restype = C.c_float
+        L.orbo_scale_factor.argtypes = [C.c_void_p]
+        L.orbo_table.argtypes = [C.c_void_p, C.c_int, f32p]
+        L.orbo_features_per_level.argtypes = [C.c_void_p, i32p]
+        L.orbo_umax.argtypes = [C.c_void_p, i32p]
+        L.orbo_level_size.argtypes = [C.c_void_p, C.c_int, i32p, i32p]
+        L.orbo_level_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int]
+        L.orbo_blurred_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.orbo_level_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orbo_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orbo_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_size_t]
+        L.orbo_border_reflect101.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+        L.orbo_fast9.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_int]
+        L.orbo_gaussian_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+        L.orbo_fast_atan2.restype = C.c_float
+        L.orbo_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orbo_distribute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orbo_extract_batch_mt.restype = C.c_double
+        L.orbo_extract_batch_mt.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                            C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, i32p]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleExtractor:
+    """CPU restatement of ORB_SLAM2::ORBextractor (reference src/ORBextractor.cc)."""
+
+    def __init__(self, nfeatures, scale_factor, nlevels, ini_th, min_th,
+                 blur_variant=BLUR_LEGACY, tie_mode=TIE_CREATION_ORDER, fma_mode=FMA_OFF):
+        self._h = lib().orbo_create(nfeatures, scale_factor, nlevels, ini_th, min_th, blur_variant, tie_mode, fma_mode)
+        if not self._h:
+            raise ValueError("bad extractor parameters")
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orbo_destroy(self._h)
+            self._h = None
+
+    def extract(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        cap = self.nfeatures + 4 * self.nlevels + 64
+        kp = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        rc = lib().orbo_extract(self._h, _ptr(img), w, h, img.strides[0], _ptr(kp), cap, C.byref(n), _ptr(desc))
+        if rc:
+            raise RuntimeError("orbo_extract failed: %d" % rc)
+        return kp[:n.value].copy(), desc[:n.value].copy()
+
+    def table(self, which):
+        out = np.zeros(self.nlevels, np.float32)
+        lib().orbo_table(self._h, which, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def scale_factor(self):
+        return lib().orbo_scale_factor(self._h)
+
+    def features_per_level(self):
+        out = np.zeros(self.nlevels, np.int32)
+        lib().orbo_features_per_level(self._h, out.ctypes.data_as(C.POINTER(C.c_int)))
+        return out
+
+    def umax(self):
+        out = np.zeros(16, np.int32)
+        lib().orbo_umax(self._h, out.ctypes.data_as(C.POINTER(C.c_int)))
+        return out
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        if lib().orbo_level_size(self._h, level, C.byref(w), C.byref(h)):
+            raise IndexError(level)
+        return w.value, h.value
+
+    def level(self, level, with_border=False):
+        w, h = self.level_size(level)
+        b = 38 if with_border else 0
+        out = np.zeros((h + b, w + b), np.uint8)
+        lib().orbo_level_copy(self._h, level, _ptr(out), out.strides[0], int(with_border))
+        return out
+
+    def blurred(self, level):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        return out if lib().orbo_blurred_copy(self._h, level, _ptr(out), out.strides[0]) == 1 else None
+
+    def candidates(self, level):
+        n = lib().orbo_level_candidates(self._h, level, None, 0)
+        out = np.zeros(max(n, 1), CAND_DTYPE)
+        lib().orbo_level_candidates(self._h, level, _ptr(out), n)
+        return out[:n]
+
+    def level_keypoints(self, level):
+        n = lib().orbo_level_keypoints(self._h, level, None, 0)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        lib().orbo_level_keypoints(self._h, level, _ptr(out), n)
+        return out[:n]
+
+
+def resize_linear_u8(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orbo_resize_linear_u8(_ptr(src), src.shape[1], src.shape[0], src.strides[0], _ptr(dst), dw, dh, dst.strides[0])
+    return dst
+
+
+def border_reflect101(src, border):
+    src = np.ascontiguousarray(src, np.uint8)
+    h, w = src.shape
+    dst = np.zeros((h + 2 * border, w + 2 * border), np.uint8)
+    lib().orbo_border_reflect101(_ptr(src), w, h, src.strides[0], _ptr(dst), dst.strides[0], border)
+    return dst
+
+
+def fast9(img, threshold):
+    img = np.ascontiguousarray(img, np.uint8)
+    n = lib().orbo_fast9(_ptr(img), img.shape[1], img.shape[0], img.strides[0], threshold, None, 0)
+    out = np.zeros(max(n, 1), CAND_DTYPE)
+    lib().orbo_fast9(_ptr(img), img.shape[1], img.shape[0], img.strides[0], threshold, _ptr(out), n)
+    return out[:n]
+
+
+def gaussian_blur7(img, variant=BLUR_LEGACY):
+    img = np.ascontiguousarray(img, np.uint8)
+    dst = np.zeros_like(img)
+    lib().orbo_gaussian_blur7(_ptr(img), img.shape[1], img.shape[0], img.strides[0], _ptr(dst), dst.strides[0], variant)
+    return dst
+
+
+def fast_atan2(y, x):
+    return lib().orbo_fast_atan2(float(y), float(x))
+
+
+def distribute(cands, min_x, max_x, min_y, max_y, n_wanted, tie_mode=TIE_CREATION_ORDER):
+    c = np.zeros(len(cands), CAND_DTYPE)
+    for i, (x, y, r) in enumerate(cands):
+        c[i] = (x, y, r)
+    out = np.zeros(max(len(cands), 1), CAND_DTYPE)
+    n = lib().orbo_distribute(_ptr(c), len(c), min_x, max_x, min_y, max_y, n_wanted, tie_mode, _ptr(out), len(out))
+    if n < 0:
+        raise RuntimeError("orbo_distribute failed: %d" % n)
+    return out[:n]
+
+
+def extract_batch_mt(params, imgs, nthreads):
+    """CPU baseline: imgs is (F,H,W) uint8; returns (seconds, counts)."""
+    imgs = np.ascontiguousarray(imgs, np.uint8)
+    f, h, w = imgs.shape
+    counts = np.zeros(f, np.int32)
+    nfeat, sf, nl, ini, mn = params
+    dt = lib().orbo_extract_batch_mt(nfeat, sf, nl, ini, mn, BLUR_LEGACY, _ptr(imgs), f, w, h,
+                                     imgs.strides[1], imgs.strides[0], nthreads, counts.ctypes.data_as(C.POINTER(C.c_int)))
+    return dt, counts
