@@ -1,0 +1,92 @@
+"""GPU parity: libORBhip (through its C ABI) against the CPU oracle on identical inputs.
+
+Bar: pyramid pixels, keypoint x/y/octave/size/response bit-exact; angle within 1e-3 degrees;
+descriptors bit-exact for >= 99.9 % of keypoints (mismatches may only come from a rounding flip of
+a rotated sample coordinate, and are reported).
+"""
+import numpy as np
+import pytest
+
+from tests.parity import DESC_MIN_EXACT, compare_outputs
+from visual_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    # name: (w, h, nfeatures, scale, levels, iniTh, minTh)
+    "C1_tum": (640, 480, 1000, 1.2, 8, 20, 7),
+    "C2_kitti": (1241, 376, 2000, 1.2, 8, 20, 7),
+    "C3_euroc": (752, 480, 1200, 1.2, 8, 20, 7),
+    "C4_1080p": (1920, 1080, 2000, 1.2, 8, 20, 7),
+    "odd_small": (333, 211, 500, 1.2, 8, 20, 7),
+    "kitti_th12": (1241, 376, 2000, 1.2, 8, 12, 7),
+}
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from oracle import orb_oracle
+    from visual_slam_amd import orbhip
+    return orbhip, orb_oracle
+
+
+def _pair(mods, cfg):
+    orbhip, O = mods
+    w, h, nf, sf, nl, ini, mn = cfg
+    return orbhip.ORBextractor(nf, sf, nl, ini, mn), O.OracleExtractor(nf, sf, nl, ini, mn)
+
+
+@pytest.mark.parametrize("name", ["C1_tum", "C2_kitti", "C3_euroc", "odd_small"])
+@pytest.mark.parametrize("kind", ["blocks", "noise", "lowc"])
+def test_stages_and_outputs(mods, name, kind):
+    cfg = CONFIGS[name]
+    g, o = _pair(mods, cfg)
+    img = synth.frame(kind, cfg[0], cfg[1], 3)
+    gkp, gdesc = g(img)
+    okp, odesc = o.extract(img)
+    for l in range(cfg[4]):
+        assert np.array_equal(g.pyramid_level(l, with_border=True), o.level(l, with_border=True)), "pyramid level %d" % l
+        assert np.array_equal(g.mvImagePyramid[l], o.level(l)), "mvImagePyramid[%d]" % l
+        gc, oc = g.debug_candidates(l), o.candidates(l)
+        assert len(gc) == len(oc), "level %d: %d candidates vs oracle %d" % (l, len(gc), len(oc))
+        assert np.array_equal(gc, oc), "candidate list of level %d" % l
+    r = compare_outputs(gkp, gdesc, okp, odesc)
+    assert r["desc_exact"] >= DESC_MIN_EXACT, r
+    print(name, kind, {k: v for k, v in r.items() if k != "desc_bad"})
+
+
+@pytest.mark.parametrize("name", ["C4_1080p", "kitti_th12"])
+def test_outputs_large(mods, name):
+    cfg = CONFIGS[name]
+    g, o = _pair(mods, cfg)
+    for kind in ("blocks", "noise"):
+        img = synth.frame(kind, cfg[0], cfg[1], 1)
+        gkp, gdesc = g(img, fetch_pyramid=False)
+        okp, odesc = o.extract(img)
+        r = compare_outputs(gkp, gdesc, okp, odesc)
+        assert r["desc_exact"] >= DESC_MIN_EXACT, r
+        print(name, kind, {k: v for k, v in r.items() if k != "desc_bad"})
+
+
+def test_const_and_empty(mods):
+    orbhip, O = mods
+    g = orbhip.ORBextractor(1000, 1.2, 8, 20, 7)
+    kp, desc = g(synth.frame("const", 640, 480))
+    assert len(kp) == 0 and desc.shape == (0, 32)
+    assert g(np.zeros((0, 0), np.uint8)) == (None, None)
+    kp, desc = g(np.zeros((40, 8), np.uint8))   # too small for a single 30-px cell on any level
+    assert len(kp) == 0
+    with pytest.raises(orbhip.OrbHipError) as ei:
+        g(np.zeros((200, 70), np.uint8))   # portrait strip: the reference divides by zero (nIni == 0)
+    assert ei.value.code == orbhip.ERR_GEOMETRY
+
+
+def test_batch_matches_single(mods):
+    orbhip, O = mods
+    g = orbhip.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=3)
+    imgs = np.stack([synth.frame(k, 640, 480, i) for i, k in enumerate(["blocks", "noise", "lowc", "const", "blocks", "blocks", "noise"])])
+    res = g.extract_batch(imgs)
+    single = orbhip.ORBextractor(1000, 1.2, 8, 20, 7)
+    for i in range(len(imgs)):
+        kp, desc = single(imgs[i], fetch_pyramid=False)
+        assert np.array_equal(res[i][0], kp) and np.array_equal(res[i][1], desc), i

@@ -1,0 +1,64 @@
+// Shared host/device definitions of libORBhip: level geometry, buffer layout, launch arguments.
+//
+// Device layout of one pyramid level of one frame ("plane"): rows of `pitch` bytes, (h + 38) rows.
+// Level pixel (x, y) sits at byte (y + ORB_OY) * pitch + (x + ORB_OX); the 19-pixel REFLECT_101
+// border the reference keeps around every level (src/ORBextractor.cc:1113-1128) therefore
+// occupies columns ORB_OX-19 .. ORB_OX-1 and ORB_OX+w .. ORB_OX+w+18. ORB_OX = 32 keeps the first
+// interior pixel 16-byte aligned; pitch is a multiple of 64. Planes are stored level-major:
+// plane(level, frame) = pyr + lv.pyr_off + frame * lv.plane_bytes.
+#pragma once
+#include <stdint.h>
+
+#define ORB_OX 32
+#define ORB_OY 19
+#define ORB_EDGE 19           // EDGE_THRESHOLD (src/ORBextractor.cc:74)
+#define ORB_MINB 16           // minBorderX/Y = EDGE_THRESHOLD-3 (src/ORBextractor.cc:773)
+#define ORB_MAX_LEVELS 16
+#define ORB_DEAD_LABEL 0x3FFFFFu   // candidate dropped by the per-cell threshold rule (22-bit label field)
+
+struct RsTab {                // one bilinear tap pair of cv::resize (8 bytes)
+    uint16_t s0, s1;          // source indices (already clamped)
+    int16_t a0, a1;           // 11-bit fixed-point weights
+};
+
+struct LevelGeom {
+    int w, h;                 // level size
+    int pitch, rows;          // plane row pitch (bytes) and row count (h + 38)
+    unsigned long long plane_bytes;
+    unsigned long long pyr_off;      // byte offset of plane(level, frame 0)
+    // FAST cell grid (src/ORBextractor.cc:773-787)
+    int maxbx, maxby;         // maxBorderX/Y = w-16, h-16
+    int ncols, nrows, wcell, hcell;
+    int cell_off;             // first cell of this level in the per-frame cell counter array
+    // candidates
+    int cand_cap;             // capacity of the candidate list of this level
+    unsigned long long cand_off;     // entry offset inside a frame's candidate block
+    // quadtree (src/ORBextractor.cc:539-563)
+    int n_ini; float hx;      // nIni, hX
+    int quota;                // mnFeaturesPerLevel[level]
+    int node_cap;             // max list length the distribution can reach
+    int kp_off;               // offset of this level's slot in the per-frame level-keypoint block
+    // output
+    float scale;              // mvScaleFactor[level]
+    float patch_size;         // (float)(int)(31 * mvScaleFactor[level])
+    // resize tables
+    int xtab_off, ytab_off;   // offsets (entries) into the RsTab buffer
+};
+
+struct PlanDev {
+    int nlevels;
+    int ini_th, min_th;
+    int cells_per_frame;             // sum over levels of ncols*nrows
+    unsigned long long cand_per_frame;   // sum over levels of cand_cap
+    int kp_per_frame;                // sum over levels of node_cap
+    int blur_taps[4];                // centre, +-1, +-2, +-3
+    int blur_ties_even;              // 1: legacy x86 column kernel (ties to even for x < (w & ~3))
+    int umax[16];
+    LevelGeom lv[ORB_MAX_LEVELS];
+};
+
+struct LevelKp {              // keypoint of one level after the quadtree, level coordinates
+    uint16_t x, y;
+    uint16_t score;
+    uint16_t pad;
+};

@@ -1,0 +1,675 @@
+// HIP kernels of libORBhip (gfx950). Integer / stencil work: no MFMA on purpose.
+//
+// Pipeline per pass over F frames (all frames of a pass share one launch, blockIdx.z/y = frame):
+//   k_level0     input image -> level 0 plane with REFLECT_101 border     (src/ORBextractor.cc:1127-1128)
+//   k_resize     level l-1 -> level l, cv::resize 8U INTER_LINEAR + border (src/ORBextractor.cc:1120-1123)
+//   k_fast       FAST-9 score, per-cell NMS, per-cell iniTh count, append  (src/ORBextractor.cc:789-829)
+//   k_quadtree   DistributeOctTree, one workgroup per (level, frame)       (src/ORBextractor.cc:539-763)
+//   k_describe   IC_Angle + 7x7 blur of the 45x45 patch + rBRIEF, one wave per keypoint
+//                                                                          (src/ORBextractor.cc:77-147,1085-1101)
+// Compiled with -ffp-contract=off: every float expression rounds exactly as written.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "orb_device.h"
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Level 0: copy of the input with the 19-px REFLECT_101 border. One thread writes one dword.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src, size_t row_stride,
+                                                size_t frame_stride, uint8_t* __restrict__ pyr,
+                                                LevelGeom g, int ndw) {
+    const int c4 = blockIdx.x * 64 + threadIdx.x;
+    const int r = blockIdx.y * 4 + threadIdx.y;
+    const int f = blockIdx.z;
+    if (c4 >= ndw || r >= g.rows) return;
+    const uint8_t* S = src + (size_t)f * frame_stride + (size_t)reflect101(r - ORB_OY, g.h) * row_stride;
+    uint32_t out = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) out |= (uint32_t)S[reflect101(c4 * 4 + b - ORB_OX, g.w)] << (8 * b);
+    uint8_t* D = pyr + g.pyr_off + (size_t)f * g.plane_bytes + (size_t)r * g.pitch;
+    reinterpret_cast<uint32_t*>(D)[c4] = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Level l from level l-1: cv::resize(8UC1, INTER_LINEAR) fixed-point arithmetic, border included
+// (a border pixel is the resized value at the reflected coordinate, which is what copyMakeBorder
+// copies there). Tap tables are built on the host exactly as OpenCV builds xofs/ialpha/yofs/ibeta.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, LevelGeom gs, LevelGeom gd,
+                                                const RsTab* __restrict__ tabs, int ndw) {
+    const int c4 = blockIdx.x * 64 + threadIdx.x;
+    const int r = blockIdx.y * 4 + threadIdx.y;
+    const int f = blockIdx.z;
+    if (c4 >= ndw || r >= gd.rows) return;
+    const RsTab ty = tabs[gd.ytab_off + reflect101(r - ORB_OY, gd.h)];
+    const uint8_t* S = pyr + gs.pyr_off + (size_t)f * gs.plane_bytes + ORB_OX;
+    const uint8_t* S0 = S + (size_t)(ty.s0 + ORB_OY) * gs.pitch;
+    const uint8_t* S1 = S + (size_t)(ty.s1 + ORB_OY) * gs.pitch;
+    const int b0 = ty.a0, b1 = ty.a1;
+    uint32_t out = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const RsTab tx = tabs[gd.xtab_off + reflect101(c4 * 4 + b - ORB_OX, gd.w)];
+        const int h0 = S0[tx.s0] * tx.a0 + S0[tx.s1] * tx.a1;
+        const int h1 = S1[tx.s0] * tx.a0 + S1[tx.s1] * tx.a1;
+        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        out |= (uint32_t)(v > 255 ? 255 : v) << (8 * b);
+    }
+    uint8_t* D = pyr + gd.pyr_off + (size_t)f * gd.plane_bytes + (size_t)r * gd.pitch;
+    reinterpret_cast<uint32_t*>(D)[c4] = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST-9/16 corner score. S = (largest t such that the pixel is a FAST-9 corner at threshold t),
+// i.e. max over the 16 nine-pixel arcs of min |centre - ring| over the arc (same sign over the arc)
+// minus 1. A pixel is a corner at threshold t iff S >= t, and cv::FAST's cornerScore equals S for
+// every corner, whatever threshold it was detected with.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fast_score16(int v, const int p[16]) {
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) d[k] = v - p[k];
+    // arcs [k..k+8] and [k+1..k+9] for even k share d[k+1..k+8]
+    int lo2[8], hi2[8];   // min/max of d[i], d[i+1] for odd i = 2j+1
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int i = 2 * j + 1;
+        lo2[j] = min(d[i & 15], d[(i + 1) & 15]);
+        hi2[j] = max(d[i & 15], d[(i + 1) & 15]);
+    }
+    int lo4[8], hi4[8];   // over d[i..i+3]
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        lo4[j] = min(lo2[j], lo2[(j + 1) & 7]);
+        hi4[j] = max(hi2[j], hi2[(j + 1) & 7]);
+    }
+    int a0 = -256, b0 = 256;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {   // k = 2j: inner eight are d[k+1..k+8]
+        const int k = 2 * j;
+        const int lo8 = min(lo4[j], lo4[(j + 2) & 7]);
+        const int hi8 = max(hi4[j], hi4[(j + 2) & 7]);
+        a0 = max(a0, min(lo8, max(d[k], d[(k + 9) & 15])));
+        b0 = min(b0, max(hi8, min(d[k], d[(k + 9) & 15])));
+    }
+    return max(a0, -b0) - 1;
+}
+
+#define FAST_TW 64
+#define FAST_TH 16
+#define FAST_IW (FAST_TW + 8)      // image tile with a 4-px halo
+#define FAST_IH (FAST_TH + 8)
+#define FAST_IP 76                 // image tile row pitch in LDS
+#define FAST_SW (FAST_TW + 2)      // score tile with a 1-px apron
+#define FAST_SH (FAST_TH + 2)
+#define FAST_SP 68
+#define FAST_STAGE 1024
+
+// One workgroup scores a 64x16 tile of the detectable area [19,w-19)x[19,h-19) of one level.
+// Non-maximum suppression and the threshold choice are per ~30-px cell in the reference (each cell
+// is a separate cv::FAST call): a corner survives iff its score is strictly above every 8-neighbour
+// that lies in the same cell, and it is emitted if score >= iniTh, or if its cell has no
+// survivor >= iniTh (decided later from cell_ini, by the consumer of the candidate list).
+__global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, LevelGeom g, int level,
+                                              int nlevels, int ini_th, int min_th, int cells_per_frame,
+                                              unsigned long long cand_per_frame,
+                                              uint2* __restrict__ cand, int* __restrict__ cand_count,
+                                              int* __restrict__ cell_ini, int* __restrict__ status) {
+    __shared__ uint8_t s_img[FAST_IH * FAST_IP];
+    __shared__ uint8_t s_sc[FAST_SH * FAST_SP];
+    __shared__ uint2 s_stage[FAST_STAGE];
+    __shared__ int s_n, s_base;
+    const int tid = threadIdx.x;
+    const int f = blockIdx.z;
+    const int tx0 = ORB_EDGE + blockIdx.x * FAST_TW;   // level coords of the tile's first pixel
+    const int ty0 = ORB_EDGE + blockIdx.y * FAST_TH;
+    const uint8_t* P = pyr + g.pyr_off + (size_t)f * g.plane_bytes;
+    if (tid == 0) s_n = 0;
+    for (int i = tid; i < FAST_IH * (FAST_IW / 4); i += 256) {
+        const int ry = i / (FAST_IW / 4), rx4 = i % (FAST_IW / 4);
+        const int row = ty0 - 4 + ry + ORB_OY;
+        const int col = tx0 - 4 + rx4 * 4 + ORB_OX;   // tx0-4+ORB_OX = 47 + 64*bx: not dword aligned
+        uint32_t v = 0;
+        if (row < g.rows) {
+            const uint8_t* R = P + (size_t)row * g.pitch;
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (col + b < g.pitch) v |= (uint32_t)R[col + b] << (8 * b);
+        }
+        *reinterpret_cast<uint32_t*>(&s_img[ry * FAST_IP + rx4 * 4]) = v;
+    }
+    __syncthreads();
+    const int x_hi = g.w - ORB_EDGE, y_hi = g.h - ORB_EDGE;
+    for (int i = tid; i < FAST_SW * FAST_SH; i += 256) {
+        const int sy = i / FAST_SW, sx = i % FAST_SW;
+        const int x = tx0 - 1 + sx, y = ty0 - 1 + sy;
+        int s = 0;
+        if (x >= ORB_EDGE && x < x_hi && y >= ORB_EDGE && y < y_hi) {
+            const uint8_t* c = &s_img[(sy + 3) * FAST_IP + sx + 3];
+            int p[16];
+            p[0] = c[3 * FAST_IP];       p[1] = c[3 * FAST_IP + 1];   p[2] = c[2 * FAST_IP + 2];   p[3] = c[FAST_IP + 3];
+            p[4] = c[3];                 p[5] = c[-FAST_IP + 3];      p[6] = c[-2 * FAST_IP + 2];  p[7] = c[-3 * FAST_IP + 1];
+            p[8] = c[-3 * FAST_IP];      p[9] = c[-3 * FAST_IP - 1];  p[10] = c[-2 * FAST_IP - 2]; p[11] = c[-FAST_IP - 3];
+            p[12] = c[-3];               p[13] = c[FAST_IP - 3];      p[14] = c[2 * FAST_IP - 2];  p[15] = c[3 * FAST_IP - 1];
+            s = fast_score16(c[0], p);
+            if (s < min_th) s = 0;
+        }
+        s_sc[sy * FAST_SP + sx] = (uint8_t)s;
+    }
+    __syncthreads();
+    for (int i = tid; i < FAST_TW * FAST_TH; i += 256) {
+        const int iy = i / FAST_TW, ix = i % FAST_TW;
+        const uint8_t* c = &s_sc[(iy + 1) * FAST_SP + ix + 1];
+        const int s = c[0];
+        if (s == 0) continue;
+        const int x = tx0 + ix, y = ty0 + iy;
+        const int ux = x - ORB_EDGE, uy = y - ORB_EDGE;
+        const int cx = ux / g.wcell, cy = uy / g.hcell;
+        const int xin = ux - cx * g.wcell, yin = uy - cy * g.hcell;
+        // neighbours outside the detectable area already score 0
+        const bool l = xin > 0, r = xin < g.wcell - 1, u = yin > 0, d = yin < g.hcell - 1;
+        bool keep = true;
+        if (l) keep = keep && s > c[-1];
+        if (r) keep = keep && s > c[1];
+        if (u) {
+            keep = keep && s > c[-FAST_SP];
+            if (l) keep = keep && s > c[-FAST_SP - 1];
+            if (r) keep = keep && s > c[-FAST_SP + 1];
+        }
+        if (d) {
+            keep = keep && s > c[FAST_SP];
+            if (l) keep = keep && s > c[FAST_SP - 1];
+            if (r) keep = keep && s > c[FAST_SP + 1];
+        }
+        if (!keep) continue;
+        if (s >= ini_th) atomicAdd(&cell_ini[(size_t)f * cells_per_frame + g.cell_off + cy * g.ncols + cx], 1);
+        const int slot = atomicAdd(&s_n, 1);
+        if (slot < FAST_STAGE) s_stage[slot] = make_uint2((uint32_t)(x - ORB_MINB) | ((uint32_t)(y - ORB_MINB) << 16), (uint32_t)s);
+    }
+    __syncthreads();
+    const int n = min(s_n, FAST_STAGE);
+    if (n == 0) return;
+    if (tid == 0) s_base = atomicAdd(&cand_count[f * nlevels + level], n);
+    __syncthreads();
+    const int base = s_base;
+    uint2* out = cand + (size_t)f * cand_per_frame + g.cand_off;
+    for (int i = tid; i < n; i += 256) {
+        if (base + i < g.cand_cap) out[base + i] = s_stage[i];
+        else atomicOr(status, 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Quadtree distribution. One workgroup per (level, frame); the node list lives in LDS.
+//
+// The reference walks a std::list and copies key vectors; here every key carries the index of the
+// list node that owns it ("label") and one round of the reference's loop is
+//   node step : decide which nodes split, in which order (= creation order of their children),
+//               build the new list = children in reverse creation order, then the unsplit nodes
+//   key step  : relabel every key to its new node and count the keys per child quadrant
+// Node counts and the "best response per node" reduction are order-independent, so the result
+// does not depend on the order in which k_fast appended the candidates. Ties between equal
+// responses go to the key that comes first in the reference's candidate order (cell row, cell
+// column, raster), encoded as `ord`. Equal-size nodes in the final expansion rounds are taken in
+// reverse creation order (the reference compares heap addresses there).
+// ------------------------------------------------------------------------------------------------
+#define QT_THREADS 256
+#define QT_FRESH 0x80000000u
+
+struct QtShared {
+    uint32_t* box[2];     // [2*M] per buffer: x0 | x1<<16, y0 | y1<<16
+    uint32_t* cnt[2];     // [M] key count | QT_FRESH
+    uint32_t* cc[2];      // [4*M] child counts; after the node step of a round: child list positions
+    uint32_t* surv;       // [M] new position of an unsplit node
+    int* kord;            // [M] split order index, or -1
+    uint32_t* ordarr;     // [M] node index by split order
+    uint32_t* cbase;      // [M] children created before this split node
+    unsigned long long* key64;  // [M] sort keys / best key per node
+};
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(v, o, 64);
+        if ((int)(threadIdx.x & 63) >= o) v += t;
+    }
+    return v;
+}
+
+// In-place exclusive scan of a[0..n) by the whole workgroup; returns the total.
+__device__ uint32_t block_excl_scan(uint32_t* a, int n, uint32_t* s_tmp) {
+    const int tid = threadIdx.x;
+    const int chunk = (n + QT_THREADS - 1) / QT_THREADS;
+    const int lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+    uint32_t s = 0;
+    for (int i = lo; i < hi; i++) s += a[i];
+    const uint32_t inc = wave_incl_scan(s);
+    if ((tid & 63) == 63) s_tmp[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < QT_THREADS / 64; w++) {
+        if (w < (tid >> 6)) off += s_tmp[w];
+        total += s_tmp[w];
+    }
+    uint32_t run = off + inc - s;
+    for (int i = lo; i < hi; i++) { const uint32_t v = a[i]; a[i] = run; run += v; }
+    __syncthreads();
+    return total;
+}
+
+__device__ __forceinline__ int qt_quadrant(uint32_t bx, uint32_t by, int x, int y) {
+    const int x0 = bx & 0xFFFF, x1 = bx >> 16, y0 = by & 0xFFFF, y1 = by >> 16;
+    const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);   // ceil(size/2)
+    return (x < mx ? 0 : 1) | (y < my ? 0 : 2);
+}
+
+__global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restrict__ plan,
+                                                         uint2* __restrict__ cand,
+                                                         const int* __restrict__ cand_count,
+                                                         const int* __restrict__ cell_ini,
+                                                         LevelKp* __restrict__ lvl_kp,
+                                                         int* __restrict__ lvl_cnt) {
+    extern __shared__ __align__(16) uint32_t smem[];
+    __shared__ uint32_t s_tmp[8];
+    __shared__ uint32_t s_red[4];
+    const int tid = threadIdx.x;
+    const int level = blockIdx.x, f = blockIdx.y;
+    const LevelGeom g = plan->lv[level];
+    const int M = g.node_cap;
+    const int N = g.quota;
+    QtShared q;
+    {
+        uint32_t* p = smem;
+        q.key64 = reinterpret_cast<unsigned long long*>(p); p += 2 * M;
+        q.box[0] = p; p += 2 * M; q.box[1] = p; p += 2 * M;
+        q.cnt[0] = p; p += M; q.cnt[1] = p; p += M;
+        q.cc[0] = p; p += 4 * M; q.cc[1] = p; p += 4 * M;
+        q.surv = p; p += M;
+        q.kord = reinterpret_cast<int*>(p); p += M;
+        q.ordarr = p; p += M;
+        q.cbase = p; p += M;
+    }
+    uint2* keys = cand + (size_t)f * plan->cand_per_frame + g.cand_off;
+    const int nkeys = min(cand_count[f * plan->nlevels + level], g.cand_cap);
+    const int* cells = cell_ini + (size_t)f * plan->cells_per_frame + g.cell_off;
+    const int ini_th = plan->ini_th;
+
+    // ---- roots (src/ORBextractor.cc:543-585)
+    int L = g.n_ini;            // length of the node array (round 0 may contain empty roots)
+    for (int i = tid; i < M; i += QT_THREADS) {
+        if (i < L) {
+            const int x0 = (int)(g.hx * (float)i), x1 = (int)(g.hx * (float)(i + 1));
+            q.box[0][2 * i] = (uint32_t)x0 | ((uint32_t)x1 << 16);
+            q.box[0][2 * i + 1] = (uint32_t)(g.maxby - ORB_MINB) << 16;
+        }
+        q.cc[0][4 * i] = q.cc[0][4 * i + 1] = q.cc[0][4 * i + 2] = q.cc[0][4 * i + 3] = 0;
+    }
+    __syncthreads();
+    for (int k = tid; k < nkeys; k += QT_THREADS) {
+        uint2 e = keys[k];
+        const int x = e.x & 0xFFFF, y = e.x >> 16, s = e.y & 0xFF;
+        const int cx = (x - 3) / g.wcell, cy = (y - 3) / g.hcell;
+        uint32_t lab = ORB_DEAD_LABEL;
+        uint32_t qd = 0;
+        if (s >= ini_th || cells[cy * g.ncols + cx] == 0) {
+            int root = (int)__fdiv_rn((float)x, g.hx);
+            root = min(max(root, 0), L - 1);
+            qd = qt_quadrant(q.box[0][2 * root], q.box[0][2 * root + 1], x, y);
+            atomicAdd(&q.cc[0][4 * root + qd], 1u);
+            lab = root;
+        }
+        keys[k].y = (uint32_t)s | (qd << 8) | (lab << 10);
+    }
+    __syncthreads();
+    for (int i = tid; i < L; i += QT_THREADS)
+        q.cnt[0][i] = (q.cc[0][4 * i] + q.cc[0][4 * i + 1] + q.cc[0][4 * i + 2] + q.cc[0][4 * i + 3]) | QT_FRESH;
+    __syncthreads();
+
+    int cur = 0;
+    int mode = 1;               // 1: expand every node with >1 key; 2: expand by size until N
+    bool done = false;
+    for (int round = 0; round < 64 && !done; round++) {
+        const int nxt = cur ^ 1;
+        // ---- A. which nodes split, and in which order
+        if (tid < 4) s_red[tid] = 0;
+        __syncthreads();
+        uint32_t prev_size_l = 0;
+        for (int i = tid; i < L; i += QT_THREADS) prev_size_l += (q.cnt[cur][i] & ~QT_FRESH) > 0;
+        if (prev_size_l) atomicAdd(&s_red[0], prev_size_l);
+        int nsplit;
+        if (mode == 1) {
+            for (int i = tid; i < L; i += QT_THREADS) q.ordarr[i] = (q.cnt[cur][i] & ~QT_FRESH) > 1;
+            __syncthreads();
+            nsplit = (int)block_excl_scan(q.ordarr, L, s_tmp);
+            for (int i = tid; i < L; i += QT_THREADS)
+                q.kord[i] = (q.cnt[cur][i] & ~QT_FRESH) > 1 ? (int)q.ordarr[i] : -1;
+            __syncthreads();
+        } else {
+            // candidates: nodes created in the previous round that hold more than one key, largest
+            // first; equal sizes: latest created first (= smaller list position)
+            uint32_t ne_l = 0;
+            for (int i = tid; i < L; i += QT_THREADS) {
+                const uint32_t c = q.cnt[cur][i];
+                const bool e = (c & QT_FRESH) && (c & ~QT_FRESH) > 1;
+                q.key64[i] = e ? (((unsigned long long)(c & ~QT_FRESH) << 32) | (0xFFFFFFFFu - (uint32_t)i)) : 0ull;
+                ne_l += e;
+            }
+            if (ne_l) atomicAdd(&s_red[1], ne_l);
+            __syncthreads();
+            const int nE = (int)s_red[1];
+            for (int i = tid; i < L; i += QT_THREADS) {
+                const unsigned long long k = q.key64[i];
+                int rank = -1;
+                if (k) {
+                    rank = 0;
+                    for (int j = 0; j < L; j++) rank += q.key64[j] > k;
+                    q.ordarr[rank] = i;
+                }
+                q.kord[i] = rank;
+            }
+            __syncthreads();
+            // growth of the list when the first r+1 candidates are split
+            for (int r = tid; r < nE; r += QT_THREADS) {
+                const int i = q.ordarr[r];
+                const uint32_t* c = &q.cc[cur][4 * i];
+                q.cbase[r] = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0) - 1;
+            }
+            __syncthreads();
+            block_excl_scan(q.cbase, nE, s_tmp);
+            // inclusive value for r = exclusive[r] + own; count r with size still below N
+            uint32_t below_l = 0;
+            const int size0 = (int)s_red[0];
+            for (int r = tid; r < nE; r += QT_THREADS) {
+                const int i = q.ordarr[r];
+                const uint32_t* c = &q.cc[cur][4 * i];
+                const int own = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0) - 1;
+                below_l += (size0 + (int)q.cbase[r] + own) < N;
+            }
+            if (below_l) atomicAdd(&s_red[2], below_l);
+            __syncthreads();
+            nsplit = min((int)s_red[2] + 1, nE);
+            for (int i = tid; i < L; i += QT_THREADS)
+                if (q.kord[i] >= nsplit) q.kord[i] = -1;
+            __syncthreads();
+        }
+        const int prev_size = (int)s_red[0];
+        // ---- B. children created before each split node (creation order = split order, n1..n4)
+        for (int i = tid; i < L; i += QT_THREADS) {
+            const int k = q.kord[i];
+            if (k >= 0) {
+                q.ordarr[k] = i;
+                const uint32_t* c = &q.cc[cur][4 * i];
+                q.cbase[k] = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0);
+            }
+        }
+        __syncthreads();
+        const int C = (int)block_excl_scan(q.cbase, nsplit, s_tmp);
+        // ---- C. unsplit, non-empty nodes keep their relative order behind the children
+        for (int i = tid; i < L; i += QT_THREADS)
+            q.surv[i] = (q.kord[i] < 0 && (q.cnt[cur][i] & ~QT_FRESH) > 0) ? 1u : 0u;
+        __syncthreads();
+        const int S = (int)block_excl_scan(q.surv, L, s_tmp);
+        const int Lnew = C + S;
+        // ---- D. build the new list
+        uint32_t expand_l = 0;
+        for (int i = tid; i < L; i += QT_THREADS) {
+            const uint32_t c = q.cnt[cur][i] & ~QT_FRESH;
+            const int k = q.kord[i];
+            if (k >= 0) {
+                const uint32_t bx = q.box[cur][2 * i], by = q.box[cur][2 * i + 1];
+                const int x0 = bx & 0xFFFF, x1 = bx >> 16, y0 = by & 0xFFFF, y1 = by >> 16;
+                const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+                int created = (int)q.cbase[k];
+#pragma unroll
+                for (int qd = 0; qd < 4; qd++) {
+                    const uint32_t n = q.cc[cur][4 * i + qd];
+                    if (n == 0) continue;
+                    const int pos = C - 1 - created++;
+                    const int cx0 = (qd & 1) ? mx : x0, cx1 = (qd & 1) ? x1 : mx;
+                    const int cy0 = (qd & 2) ? my : y0, cy1 = (qd & 2) ? y1 : my;
+                    q.box[nxt][2 * pos] = (uint32_t)cx0 | ((uint32_t)cx1 << 16);
+                    q.box[nxt][2 * pos + 1] = (uint32_t)cy0 | ((uint32_t)cy1 << 16);
+                    q.cnt[nxt][pos] = n | QT_FRESH;
+                    q.cc[cur][4 * i + qd] = (uint32_t)pos;
+                    expand_l += n > 1;
+                }
+            } else if (c > 0) {
+                const int pos = C + (int)q.surv[i];
+                q.box[nxt][2 * pos] = q.box[cur][2 * i];
+                q.box[nxt][2 * pos + 1] = q.box[cur][2 * i + 1];
+                q.cnt[nxt][pos] = c;
+                q.surv[i] = (uint32_t)pos;
+            }
+        }
+        if (expand_l) atomicAdd(&s_red[3], expand_l);
+        for (int i = tid; i < 4 * Lnew; i += QT_THREADS) q.cc[nxt][i] = 0;
+        __syncthreads();
+        const int to_expand = (int)s_red[3];
+        // ---- finish test (src/ORBextractor.cc:669-673, 734-735)
+        if (Lnew >= N || Lnew == prev_size) done = true;
+        else if (mode == 1 && Lnew + 3 * to_expand > N) mode = 2;
+        // ---- E. keys follow their nodes
+        if (!done) {
+            for (int k = tid; k < nkeys; k += QT_THREADS) {
+                const uint2 e = keys[k];
+                const uint32_t lab = e.y >> 10;
+                if (lab == ORB_DEAD_LABEL) continue;
+                const uint32_t qd = (e.y >> 8) & 3;
+                const uint32_t nl = q.kord[lab] >= 0 ? q.cc[cur][4 * lab + qd] : q.surv[lab];
+                const int x = e.x & 0xFFFF, y = e.x >> 16;
+                const uint32_t nq = qt_quadrant(q.box[nxt][2 * nl], q.box[nxt][2 * nl + 1], x, y);
+                atomicAdd(&q.cc[nxt][4 * nl + nq], 1u);
+                keys[k].y = (e.y & 0xFF) | (nq << 8) | (nl << 10);
+            }
+        } else {
+            // ---- best response per node, first in candidate order on ties (src/ORBextractor.cc:744-760)
+            for (int i = tid; i < Lnew; i += QT_THREADS) q.key64[i] = 0ull;
+            __syncthreads();
+            for (int k = tid; k < nkeys; k += QT_THREADS) {
+                const uint2 e = keys[k];
+                const uint32_t lab = e.y >> 10;
+                if (lab == ORB_DEAD_LABEL) continue;
+                const uint32_t qd = (e.y >> 8) & 3;
+                const uint32_t nl = q.kord[lab] >= 0 ? q.cc[cur][4 * lab + qd] : q.surv[lab];
+                const int x = e.x & 0xFFFF, y = e.x >> 16;
+                const int cx = (x - 3) / g.wcell, cy = (y - 3) / g.hcell;
+                const uint32_t ord = (uint32_t)(((cy * g.ncols + cx) * g.hcell + (y - 3 - cy * g.hcell)) * g.wcell +
+                                                (x - 3 - cx * g.wcell));
+                atomicMax(&q.key64[nl], ((unsigned long long)(e.y & 0xFF) << 32) | (0xFFFFFFFFu - ord));
+            }
+        }
+        __syncthreads();
+        L = Lnew;
+        cur = nxt;
+    }
+    // ---- output in list order
+    LevelKp* out = lvl_kp + (size_t)f * plan->kp_per_frame + g.kp_off;
+    for (int i = tid; i < L; i += QT_THREADS) {
+        const unsigned long long b = q.key64[i];
+        const uint32_t ord = 0xFFFFFFFFu - (uint32_t)b;
+        const int xin = ord % g.wcell;
+        uint32_t t = ord / g.wcell;
+        const int yin = t % g.hcell;
+        t /= g.hcell;
+        const int cx = t % g.ncols, cy = t / g.ncols;
+        LevelKp kp;
+        kp.x = (uint16_t)(cx * g.wcell + xin + 3 + ORB_MINB);
+        kp.y = (uint16_t)(cy * g.hcell + yin + 3 + ORB_MINB);
+        kp.score = (uint16_t)(b >> 32);
+        kp.pad = 0;
+        out[i] = kp;
+    }
+    if (tid == 0) lvl_cnt[f * plan->nlevels + level] = L;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Orientation + descriptor, one wave per keypoint, four keypoints per workgroup.
+// The reference blurs whole levels and then samples 512 points per keypoint; only the 39x39
+// neighbourhood of a keypoint is ever sampled, so each wave stages the 45x45 raw patch in LDS,
+// runs the horizontal 7-tap pass over it (45x39, kept as exact 16-bit sums) and evaluates the
+// vertical pass only at the sampled positions. Bits are packed with wave ballots.
+// ------------------------------------------------------------------------------------------------
+#define DS_RAW_P 52               // raw patch pitch (13 dwords)
+#define DS_RAW_BYTES (45 * DS_RAW_P)
+#define DS_HP_P 40                // horizontal-pass pitch (u16 entries)
+#define DS_HP_ENTRIES (45 * DS_HP_P)
+
+__device__ __align__(16) const signed char d_pattern[1024] = {
+#include "../../include/orb_pattern_31.inc"
+};
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {   // cv::fastAtan2
+    const float s = (float)(180 / 3.141592653589793238462643383279502884);
+    const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s;
+    const float p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = __fdiv_rn(ax, ay + eps);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ plan,
+                                                  const uint8_t* __restrict__ pyr,
+                                                  const LevelKp* __restrict__ lvl_kp,
+                                                  const int* __restrict__ lvl_cnt,
+                                                  float* __restrict__ out_kp,   // 7 floats per keypoint
+                                                  uint8_t* __restrict__ out_desc, int* __restrict__ out_count,
+                                                  int cap, int frame0, int* __restrict__ status) {
+    __shared__ __align__(16) uint8_t s_raw[4][DS_RAW_BYTES];
+    __shared__ uint16_t s_hp[4][DS_HP_ENTRIES];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int f = blockIdx.y;
+    const int idx = blockIdx.x * 4 + wv;
+    const int nl = plan->nlevels;
+    // locate (level, j) of output keypoint idx: levels are concatenated in order (src/ORBextractor.cc:1076-1104)
+    int level = -1, j = idx, total = 0;
+    for (int l = 0; l < nl; l++) {
+        const int c = lvl_cnt[f * nl + l];
+        if (level < 0) {
+            if (j < c) level = l; else j -= c;
+        }
+        total += c;
+    }
+    if (idx == 0 && lane == 0) {
+        out_count[frame0 + f] = min(total, cap);
+        if (total > cap) atomicOr(status, 2);
+    }
+    // every wave stays until the end (workgroup barriers below); invalid waves work on keypoint 0
+    // of level 0 geometry with all stores suppressed
+    const bool valid = level >= 0 && idx < cap;
+    if (!valid) { level = 0; j = 0; }
+    const LevelGeom g = plan->lv[level];
+    LevelKp kp = lvl_kp[(size_t)f * plan->kp_per_frame + g.kp_off + j];
+    if (!valid) { kp.x = 22; kp.y = 22; kp.score = 0; }   // any in-bounds position
+    const int kx = kp.x, ky = kp.y;
+    const uint8_t* P = pyr + g.pyr_off + (size_t)f * g.plane_bytes;
+    // ---- stage rows ky-22..ky+22, 13 aligned dwords per row starting at or before column kx-22
+    const int col0 = kx - 22 + ORB_OX;            // >= 29: keypoints are >= 19 px from the level edge
+    const int colA = col0 & ~3, off = col0 & 3;
+    uint8_t* raw = s_raw[wv];
+    for (int i = lane; i < 45 * 13; i += 64) {
+        const int r = i / 13, c = i - r * 13;
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(P + (size_t)(ky - 22 + r + ORB_OY) * g.pitch + colA + c * 4);
+        *reinterpret_cast<uint32_t*>(&raw[r * DS_RAW_P + c * 4]) = v;
+    }
+    __syncthreads();
+    // ---- IC_Angle (src/ORBextractor.cc:77-104): integer moments over the 749-px disc
+    int m10 = 0, m01 = 0;
+    {
+        const int u = (lane & 31) - 15;           // column offset; lane 31/63 idle
+        const int half = lane >> 5;               // 0: rows -15..0, 1: rows 1..15
+        if (u <= 15) {
+            const int au = u < 0 ? -u : u;
+            for (int t = 0; t < 16; t++) {
+                const int v = half ? t + 1 : -t;
+                if (half && t == 15) break;
+                const int av = v < 0 ? -v : v;
+                if (au <= plan->umax[av]) {
+                    const int I = raw[(22 + v) * DS_RAW_P + off + 22 + u];
+                    m10 += u * I;
+                    m01 += v * I;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            m10 += __shfl_xor(m10, o, 64);
+            m01 += __shfl_xor(m01, o, 64);
+        }
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    // ---- horizontal blur pass: hp[r][c] for rows ky-22..ky+22, columns kx-19..kx+19
+    const int t0 = plan->blur_taps[0], t1 = plan->blur_taps[1], t2 = plan->blur_taps[2], t3 = plan->blur_taps[3];
+    uint16_t* hp = s_hp[wv];
+    for (int i = lane; i < 45 * 39; i += 64) {
+        const int r = i / 39, c = i - r * 39;
+        const uint8_t* s = &raw[r * DS_RAW_P + off + c];   // taps at c .. c+6, centre c+3
+        const int acc = t0 * s[3] + t1 * (s[2] + s[4]) + t2 * (s[1] + s[5]) + t3 * (s[0] + s[6]);
+        hp[r * DS_HP_P + c] = (uint16_t)acc;
+    }
+    __syncthreads();
+    // ---- steered BRIEF (src/ORBextractor.cc:107-147)
+    const float factorPI = (float)(3.141592653589793238462643383279502884 / 180.f);
+    const float ang_rad = angle * factorPI;
+    const float a = (float)cos((double)ang_rad), b = (float)sin((double)ang_rad);
+    const int wv4 = g.w & ~3;
+    const int ties_even = plan->blur_ties_even;
+    unsigned long long bits[4];
+#pragma unroll
+    for (int rnd = 0; rnd < 4; rnd++) {
+        const int pair = rnd * 64 + lane;
+        const int pk = *reinterpret_cast<const int*>(&d_pattern[4 * pair]);
+        int val[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const float px = (float)(signed char)(pk >> (16 * e));
+            const float py = (float)(signed char)(pk >> (16 * e + 8));
+            const int ry = (int)rintf(px * b + py * a);
+            const int rx = (int)rintf(px * a - py * b);
+            const uint16_t* h = &hp[(ry + 22) * DS_HP_P + rx + 19];
+            const int acc = t0 * h[0] + t1 * (h[-DS_HP_P] + h[DS_HP_P]) + t2 * (h[-2 * DS_HP_P] + h[2 * DS_HP_P]) +
+                            t3 * (h[-3 * DS_HP_P] + h[3 * DS_HP_P]);
+            int qv = acc >> 16;
+            const int rem = acc & 0xFFFF;
+            if (rem > 32768) qv++;
+            else if (rem == 32768) qv += (ties_even && (kx + rx) < wv4) ? (qv & 1) : 1;
+            val[e] = qv > 255 ? 255 : qv;
+        }
+        bits[rnd] = __ballot(val[0] < val[1]);
+    }
+    const size_t o = (size_t)(frame0 + f) * cap + idx;
+    if (!valid) return;
+    if (lane < 4) {
+        const unsigned long long v = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+        reinterpret_cast<unsigned long long*>(out_desc + o * 32)[lane] = v;
+    }
+    if (lane == 0) {
+        float* K = out_kp + o * 7;
+        const float sc = g.scale;
+        K[0] = level ? (float)kx * sc : (float)kx;
+        K[1] = level ? (float)ky * sc : (float)ky;
+        K[2] = g.patch_size;
+        K[3] = angle;
+        K[4] = (float)kp.score;
+        reinterpret_cast<int*>(K)[5] = level;
+        reinterpret_cast<int*>(K)[6] = -1;
+    }
+}

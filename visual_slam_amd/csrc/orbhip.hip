@@ -1,0 +1,575 @@
+// libORBhip — host side of the C ABI declared in include/orbhip.h.
+//
+// Mirrors ORB_SLAM2::ORBextractor (reference src/ORBextractor.cc): the constructor tables are
+// computed here exactly as the reference computes them; operator() becomes a fixed sequence of
+// kernel launches over a pass of up to max_batch frames. There is no CPU fallback: every entry
+// point fails with an error code when HIP is unavailable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/orbhip.h"
+#include "orb_device.h"
+#include "orb_kernels.h"
+
+namespace {
+
+inline int cv_round(double v) { return (int)std::lrint(v); }
+inline int cv_floor(double v) { int i = (int)v; return i - (i > v); }
+inline int cv_ceil(double v) { int i = (int)v; return i + (i < v); }
+inline short sat_short(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
+enum KernelClass { KC_LEVEL0 = 0, KC_RESIZE, KC_FAST, KC_QUADTREE, KC_DESCRIBE, KC_COUNT };
+const char* const kKernelNames[KC_COUNT] = {"k_level0", "k_resize", "k_fast", "k_quadtree", "k_describe"};
+
+struct TimedSpan { int kc; hipEvent_t a, b; };
+
+} // namespace
+
+struct orbhip_extractor {
+    orbhip_params prm;
+    double scale_factor_d;
+    std::vector<float> sf, inv_sf, sigma2, inv_sigma2;
+    std::vector<int> per_level;
+    int umax[16];
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // plan for the current image size
+    int plan_w = 0, plan_h = 0, plan_frames = 0;
+    PlanDev plan;
+    size_t pyr_bytes_per_frame = 0;
+    PlanDev* d_plan = nullptr;
+    RsTab* d_tabs = nullptr;
+    uint8_t* d_pyr = nullptr;
+    uint2* d_cand = nullptr;
+    int* d_cand_count = nullptr;   // [frames][nlevels]
+    int* d_cell_ini = nullptr;     // [frames][cells_per_frame]
+    LevelKp* d_lvl_kp = nullptr;   // [frames][kp_per_frame]
+    int* d_lvl_cnt = nullptr;      // [frames][nlevels]
+    int* d_status = nullptr;       // bit0 candidate overflow, bit1 output capacity
+    size_t qt_lds = 0;
+    int last_pass_frames = 0;
+    // staging for the host entry points
+    uint8_t* d_in = nullptr; size_t d_in_bytes = 0;
+    float* d_out_kp = nullptr; uint8_t* d_out_desc = nullptr; int* d_out_cnt = nullptr;
+    size_t d_out_frames = 0; int d_out_cap = 0;
+    // timing
+    bool timing = false;
+    std::vector<TimedSpan> spans;
+    std::vector<hipEvent_t> event_pool;
+    float kc_ms[KC_COUNT] = {0};
+    int kc_launches[KC_COUNT] = {0};
+};
+
+namespace {
+
+#define HIP_TRY(e, call)                                                                     \
+    do {                                                                                     \
+        hipError_t _s = (call);                                                              \
+        if (_s != hipSuccess) {                                                              \
+            (e)->err = std::string(#call) + ": " + hipGetErrorString(_s);                    \
+            return ORBHIP_ERR_HIP;                                                           \
+        }                                                                                    \
+    } while (0)
+
+template <typename T>
+void dfree(T*& p) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+void free_plan(orbhip_extractor* e) {
+    dfree(e->d_plan); dfree(e->d_tabs); dfree(e->d_pyr); dfree(e->d_cand); dfree(e->d_cand_count);
+    dfree(e->d_cell_ini); dfree(e->d_lvl_kp); dfree(e->d_lvl_cnt);
+    e->plan_w = e->plan_h = e->plan_frames = 0;
+}
+
+// Tap tables of cv::resize(8UC1, INTER_LINEAR): same construction as OpenCV's xofs/ialpha and
+// yofs/ibeta, with the clamping the row/column loops apply folded into the indices.
+void build_resize_tabs(int sw, int sh, int dw, int dh, RsTab* xt, RsTab* yt) {
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xt[dx].s0 = (uint16_t)sx;
+        xt[dx].s1 = (uint16_t)std::min(sx + 1, sw - 1);
+        xt[dx].a0 = sat_short(cv_round((1.f - fx) * 2048));
+        xt[dx].a1 = sat_short(cv_round(fx * 2048));
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor(fy);
+        fy -= sy;
+        yt[dy].s0 = (uint16_t)std::min(std::max(sy, 0), sh - 1);
+        yt[dy].s1 = (uint16_t)std::min(std::max(sy + 1, 0), sh - 1);
+        yt[dy].a0 = sat_short(cv_round((1.f - fy) * 2048));
+        yt[dy].a1 = sat_short(cv_round(fy * 2048));
+    }
+}
+
+void blur_taps(int variant, int taps[4]) {   // cv::getGaussianKernel(7, 2, CV_32F) scaled by 256
+    double k[7], sum = 0;
+    for (int i = 0; i < 7; i++) { double x = i - 3; float t = (float)std::exp(-0.5 / 4.0 * x * x); k[i] = t; sum += t; }
+    const double scale = 1. / sum;
+    int q[7], qs = 0;
+    for (int i = 0; i < 7; i++) { q[i] = cv_round((float)(k[i] * scale) * 256.f); qs += q[i]; }
+    if (variant == ORBHIP_BLUR_FIXEDPOINT) q[3] -= qs - 256;
+    taps[0] = q[3]; taps[1] = q[2]; taps[2] = q[1]; taps[3] = q[0];
+}
+
+int ensure_plan(orbhip_extractor* e, int w, int h, int frames) {
+    if (e->plan_w == w && e->plan_h == h && e->plan_frames >= frames) return ORBHIP_OK;
+    if (w > 16384 || h > 16384) { e->err = "image larger than 16384 px"; return ORBHIP_ERR_GEOMETRY; }
+    free_plan(e);
+    PlanDev& P = e->plan;
+    std::memset(&P, 0, sizeof(P));
+    const int nl = e->prm.nlevels;
+    P.nlevels = nl;
+    P.ini_th = e->prm.ini_th_fast;
+    P.min_th = e->prm.min_th_fast;
+    blur_taps(e->prm.blur_variant, P.blur_taps);
+    P.blur_ties_even = e->prm.blur_variant == ORBHIP_BLUR_LEGACY;
+    std::memcpy(P.umax, e->umax, sizeof(P.umax));
+    size_t pyr_off = 0, cand_off = 0;
+    int cell_off = 0, kp_off = 0, tab_off = 0;
+    int max_nodes = 0;
+    for (int l = 0; l < nl; l++) {
+        LevelGeom& g = P.lv[l];
+        g.w = cv_round((float)w * e->inv_sf[l]);          // src/ORBextractor.cc:1111-1112
+        g.h = cv_round((float)h * e->inv_sf[l]);
+        if (g.w < 1 || g.h < 1) { e->err = "pyramid level collapses to zero size"; return ORBHIP_ERR_GEOMETRY; }
+        g.pitch = (ORB_OX + g.w + ORB_EDGE + 63) / 64 * 64;
+        g.rows = g.h + 2 * ORB_EDGE;
+        g.plane_bytes = (unsigned long long)g.pitch * g.rows;
+        g.pyr_off = pyr_off;
+        pyr_off += g.plane_bytes * frames;
+        g.maxbx = g.w - ORB_EDGE + 3;                      // src/ORBextractor.cc:775-776
+        g.maxby = g.h - ORB_EDGE + 3;
+        const float width = (float)(g.maxbx - ORB_MINB), height = (float)(g.maxby - ORB_MINB);
+        g.ncols = width > 0 ? (int)(width / 30.f) : 0;     // src/ORBextractor.cc:784-787
+        g.nrows = height > 0 ? (int)(height / 30.f) : 0;
+        if (g.ncols < 1 || g.nrows < 1) {
+            // the reference visits no cell on such a level: it contributes no keypoints
+            g.ncols = g.nrows = 0; g.wcell = g.hcell = 1;
+            g.n_ini = 0; g.hx = 1.f; g.node_cap = 1; g.cand_cap = 1;
+        } else {
+            g.wcell = (int)std::ceil(width / g.ncols);
+            g.hcell = (int)std::ceil(height / g.nrows);
+            g.n_ini = (int)std::round(width / (float)(g.maxby - ORB_MINB));   // src/ORBextractor.cc:543
+            if (g.n_ini < 1) { e->err = "image too narrow for the quadtree (nIni == 0)"; return ORBHIP_ERR_GEOMETRY; }
+            g.hx = width / (float)g.n_ini;                                  // src/ORBextractor.cc:545
+            // strict local maxima inside a cell: at most one per 2x2 block
+            const int dw = g.w - 2 * ORB_EDGE, dh = g.h - 2 * ORB_EDGE;
+            g.cand_cap = ((dw + 1) / 2 + g.ncols) * ((dh + 1) / 2 + g.nrows);
+            g.node_cap = std::max(e->per_level[l] + 3, 4 * g.n_ini) + 1;
+        }
+        g.cell_off = cell_off; cell_off += g.ncols * g.nrows;
+        g.cand_off = cand_off; cand_off += g.cand_cap;
+        g.quota = e->per_level[l];
+        g.kp_off = kp_off; kp_off += g.node_cap;
+        g.scale = e->sf[l];
+        g.patch_size = (float)(int)(31 * e->sf[l]);        // src/ORBextractor.cc:837
+        g.xtab_off = tab_off; tab_off += g.w;
+        g.ytab_off = tab_off; tab_off += g.h;
+        max_nodes = std::max(max_nodes, g.node_cap);
+    }
+    P.cells_per_frame = std::max(cell_off, 1);
+    P.cand_per_frame = cand_off;
+    P.kp_per_frame = kp_off;
+    e->pyr_bytes_per_frame = pyr_off / frames;
+    e->qt_lds = (size_t)max_nodes * 4 * (2 + 4 + 2 + 8 + 1 + 1 + 1 + 1);
+    if (e->qt_lds > 160 * 1024 - 256) { e->err = "nfeatures per level too large for the on-chip quadtree"; return ORBHIP_ERR_ARG; }
+    std::vector<RsTab> tabs((size_t)std::max(tab_off, 1));
+    for (int l = 1; l < nl; l++)
+        build_resize_tabs(P.lv[l - 1].w, P.lv[l - 1].h, P.lv[l].w, P.lv[l].h, &tabs[P.lv[l].xtab_off], &tabs[P.lv[l].ytab_off]);
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipMalloc(&e->d_plan, sizeof(PlanDev)));
+    HIP_TRY(e, hipMalloc(&e->d_tabs, tabs.size() * sizeof(RsTab)));
+    HIP_TRY(e, hipMalloc(&e->d_pyr, pyr_off + 64));
+    HIP_TRY(e, hipMalloc(&e->d_cand, (size_t)P.cand_per_frame * frames * sizeof(uint2)));
+    HIP_TRY(e, hipMalloc(&e->d_cand_count, (size_t)frames * nl * sizeof(int)));
+    HIP_TRY(e, hipMalloc(&e->d_cell_ini, (size_t)frames * P.cells_per_frame * sizeof(int)));
+    HIP_TRY(e, hipMalloc(&e->d_lvl_kp, (size_t)frames * P.kp_per_frame * sizeof(LevelKp)));
+    HIP_TRY(e, hipMalloc(&e->d_lvl_cnt, (size_t)frames * nl * sizeof(int)));
+    HIP_TRY(e, hipMemcpyAsync(e->d_plan, &P, sizeof(PlanDev), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->d_tabs, tabs.data(), tabs.size() * sizeof(RsTab), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->d_lvl_kp, 0, (size_t)frames * P.kp_per_frame * sizeof(LevelKp), e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (e->qt_lds > 64 * 1024)
+        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->qt_lds));
+    e->plan_w = w; e->plan_h = h; e->plan_frames = frames;
+    return ORBHIP_OK;
+}
+
+hipEvent_t get_event(orbhip_extractor* e) {
+    if (!e->event_pool.empty()) { hipEvent_t ev = e->event_pool.back(); e->event_pool.pop_back(); return ev; }
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreate(&ev);
+    return ev;
+}
+
+struct SpanGuard {   // records a pair of events around a group of launches when timing is on
+    orbhip_extractor* e; hipStream_t s; int kc; hipEvent_t a = nullptr;
+    SpanGuard(orbhip_extractor* e_, hipStream_t s_, int kc_) : e(e_), s(s_), kc(kc_) {
+        if (e->timing) { a = get_event(e); (void)hipEventRecord(a, s); }
+    }
+    ~SpanGuard() {
+        if (e->timing) { hipEvent_t b = get_event(e); (void)hipEventRecord(b, s); e->spans.push_back(TimedSpan{kc, a, b}); e->kc_launches[kc]++; }
+    }
+};
+
+// One pass: `frames` frames starting at device pointer d_imgs; outputs written at frame index frame0.
+int run_pass(orbhip_extractor* e, hipStream_t s, const uint8_t* d_imgs, int frames, size_t row_stride,
+             size_t frame_stride, float* d_kp, uint8_t* d_desc, int* d_counts, int cap, int frame0) {
+    const PlanDev& P = e->plan;
+    const int nl = P.nlevels;
+    HIP_TRY(e, hipMemsetAsync(e->d_cand_count, 0, (size_t)frames * nl * sizeof(int), s));
+    HIP_TRY(e, hipMemsetAsync(e->d_cell_ini, 0, (size_t)frames * P.cells_per_frame * sizeof(int), s));
+    const dim3 blk2(64, 4);
+    {
+        SpanGuard t(e, s, KC_LEVEL0);
+        const LevelGeom& g = P.lv[0];
+        const int ndw = (ORB_OX + g.w + ORB_EDGE + 3) / 4;
+        hipLaunchKernelGGL(k_level0, dim3((ndw + 63) / 64, (g.rows + 3) / 4, frames), blk2, 0, s,
+                           d_imgs, row_stride, frame_stride, e->d_pyr, g, ndw);
+    }
+    for (int l = 1; l < nl; l++) {
+        SpanGuard t(e, s, KC_RESIZE);
+        const LevelGeom& g = P.lv[l];
+        const int ndw = (ORB_OX + g.w + ORB_EDGE + 3) / 4;
+        hipLaunchKernelGGL(k_resize, dim3((ndw + 63) / 64, (g.rows + 3) / 4, frames), blk2, 0, s,
+                           e->d_pyr, P.lv[l - 1], g, e->d_tabs, ndw);
+    }
+    for (int l = 0; l < nl; l++) {
+        const LevelGeom& g = P.lv[l];
+        if (g.ncols < 1) continue;
+        const int dw = g.w - 2 * ORB_EDGE, dh = g.h - 2 * ORB_EDGE;
+        if (dw < 1 || dh < 1) continue;
+        SpanGuard t(e, s, KC_FAST);
+        hipLaunchKernelGGL(k_fast, dim3((dw + FAST_TW - 1) / FAST_TW, (dh + FAST_TH - 1) / FAST_TH, frames), dim3(256), 0, s,
+                           e->d_pyr, g, l, nl, P.ini_th, P.min_th, P.cells_per_frame, P.cand_per_frame,
+                           e->d_cand, e->d_cand_count, e->d_cell_ini, e->d_status);
+    }
+    {
+        SpanGuard t(e, s, KC_QUADTREE);
+        hipLaunchKernelGGL(k_quadtree, dim3(nl, frames), dim3(QT_THREADS), e->qt_lds, s,
+                           e->d_plan, e->d_cand, e->d_cand_count, e->d_cell_ini, e->d_lvl_kp, e->d_lvl_cnt);
+    }
+    {
+        SpanGuard t(e, s, KC_DESCRIBE);
+        const int maxkp = std::min(cap, P.kp_per_frame);
+        hipLaunchKernelGGL(k_describe, dim3((maxkp + 3) / 4, frames), dim3(256), 0, s,
+                           e->d_plan, e->d_pyr, e->d_lvl_kp, e->d_lvl_cnt, d_kp, d_desc, d_counts, cap, frame0, e->d_status);
+    }
+    HIP_TRY(e, hipGetLastError());
+    e->last_pass_frames = frames;
+    return ORBHIP_OK;
+}
+
+int check_status(orbhip_extractor* e) {
+    int st = 0;
+    HIP_TRY(e, hipMemcpy(&st, e->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st) {
+        (void)hipMemset(e->d_status, 0, sizeof(int));
+        e->err = (st & 1) ? "internal candidate capacity exceeded" : "output capacity (cap) too small";
+        return ORBHIP_ERR_CAPACITY;
+    }
+    return ORBHIP_OK;
+}
+
+void collect_timing(orbhip_extractor* e) {
+    for (TimedSpan& sp : e->spans) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) e->kc_ms[sp.kc] += ms;
+        e->event_pool.push_back(sp.a);
+        e->event_pool.push_back(sp.b);
+    }
+    e->spans.clear();
+}
+
+} // namespace
+
+extern "C" {
+
+int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
+    if (!p || !out) return ORBHIP_ERR_ARG;
+    *out = nullptr;
+    if (p->nfeatures < 1 || p->nlevels < 1 || p->nlevels > ORB_MAX_LEVELS || !(p->scale_factor > 1.0f) ||
+        p->ini_th_fast < 1 || p->min_th_fast < 1 || p->ini_th_fast > 255 || p->min_th_fast > p->ini_th_fast)
+        return ORBHIP_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || p->device < 0 || p->device >= ndev) return ORBHIP_ERR_NO_DEVICE;
+    orbhip_extractor* e = new orbhip_extractor;
+    e->prm = *p;
+    if (e->prm.max_batch < 1) e->prm.max_batch = 64;
+    e->device = p->device;
+    const int nl = p->nlevels;
+    // src/ORBextractor.cc:412-431 (scaleFactor is a double member initialised from the float argument)
+    e->scale_factor_d = p->scale_factor;
+    e->sf.resize(nl); e->sigma2.resize(nl); e->inv_sf.resize(nl); e->inv_sigma2.resize(nl);
+    e->sf[0] = 1.0f; e->sigma2[0] = 1.0f;
+    for (int i = 1; i < nl; i++) {
+        e->sf[i] = (float)(e->sf[i - 1] * e->scale_factor_d);
+        e->sigma2[i] = e->sf[i] * e->sf[i];
+    }
+    for (int i = 0; i < nl; i++) {
+        e->inv_sf[i] = 1.0f / e->sf[i];
+        e->inv_sigma2[i] = 1.0f / e->sigma2[i];
+    }
+    // src/ORBextractor.cc:435-446
+    e->per_level.resize(nl);
+    const float factor = (float)(1.0f / e->scale_factor_d);
+    float desired = p->nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
+    int sum = 0;
+    for (int l = 0; l < nl - 1; l++) {
+        e->per_level[l] = cv_round(desired);
+        sum += e->per_level[l];
+        desired *= factor;
+    }
+    e->per_level[nl - 1] = std::max(p->nfeatures - sum, 0);
+    // src/ORBextractor.cc:454-469
+    int um[18] = {0};
+    const int hp = 15;
+    int v, v0, vmax = cv_floor(hp * std::sqrt(2.f) / 2 + 1), vmin = cv_ceil(hp * std::sqrt(2.f) / 2);
+    for (v = 0; v <= vmax; ++v) um[v] = cv_round(std::sqrt((double)hp * hp - v * v));
+    for (v = hp, v0 = 0; v >= vmin; --v) {
+        while (um[v0] == um[v0 + 1]) ++v0;
+        um[v] = v0;
+        ++v0;
+    }
+    std::memcpy(e->umax, um, sizeof(e->umax));
+    if (hipSetDevice(e->device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&e->d_status, sizeof(int)) != hipSuccess || hipMemset(e->d_status, 0, sizeof(int)) != hipSuccess) {
+        delete e;
+        return ORBHIP_ERR_HIP;
+    }
+    *out = e;
+    return ORBHIP_OK;
+}
+
+int orbhip_destroy(orbhip_extractor* e) {
+    if (!e) return ORBHIP_ERR_ARG;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    collect_timing(e);
+    for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
+    free_plan(e);
+    dfree(e->d_status); dfree(e->d_in); dfree(e->d_out_kp); dfree(e->d_out_desc); dfree(e->d_out_cnt);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return ORBHIP_OK;
+}
+
+int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int nframes, int width, int height,
+                                size_t row_stride, size_t frame_stride, orbhip_keypoint* d_kp, uint8_t* d_desc,
+                                int* d_counts, int cap, void* stream) {
+    if (!e || !d_kp || !d_desc || !d_counts || cap < 1 || nframes < 0) return ORBHIP_ERR_ARG;
+    if (!d_imgs || width <= 0 || height <= 0 || nframes == 0) return ORBHIP_ERR_EMPTY;
+    if (row_stride < (size_t)width) return ORBHIP_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    const int chunk = std::min(nframes, e->prm.max_batch);
+    if (e->plan_w != width || e->plan_h != height || e->plan_frames < chunk) {
+        // a new plan frees the old workspaces: nothing may still be running on them
+        HIP_TRY(e, hipDeviceSynchronize());
+        int rc = ensure_plan(e, width, height, chunk);
+        if (rc) return rc;
+    }
+    for (int f0 = 0; f0 < nframes; f0 += chunk) {
+        const int n = std::min(chunk, nframes - f0);
+        int rc = run_pass(e, s, d_imgs + (size_t)f0 * frame_stride, n, row_stride, frame_stride,
+                          reinterpret_cast<float*>(d_kp), d_desc, d_counts, cap, f0);
+        if (rc) return rc;
+    }
+    return ORBHIP_OK;
+}
+
+int orbhip_synchronize(orbhip_extractor* e) {
+    if (!e) return ORBHIP_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipDeviceSynchronize());
+    collect_timing(e);
+    return check_status(e);
+}
+
+int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int nframes, int width, int height,
+                         size_t row_stride, size_t frame_stride, orbhip_keypoint* kp, uint8_t* desc,
+                         int* counts, int cap) {
+    if (!e || !kp || !desc || !counts || cap < 1 || nframes < 0) return ORBHIP_ERR_ARG;
+    if (!imgs || width <= 0 || height <= 0 || nframes == 0) return ORBHIP_ERR_EMPTY;
+    if (row_stride < (size_t)width) return ORBHIP_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    const size_t dev_row = (size_t)(width + 3) & ~(size_t)3, dev_frame = dev_row * height;
+    const size_t need = dev_frame * nframes;
+    if (need > e->d_in_bytes) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        dfree(e->d_in);
+        HIP_TRY(e, hipMalloc(&e->d_in, need));
+        e->d_in_bytes = need;
+    }
+    if ((size_t)nframes > e->d_out_frames || cap != e->d_out_cap) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        dfree(e->d_out_kp); dfree(e->d_out_desc); dfree(e->d_out_cnt);
+        HIP_TRY(e, hipMalloc(&e->d_out_kp, (size_t)nframes * cap * sizeof(orbhip_keypoint)));
+        HIP_TRY(e, hipMalloc(&e->d_out_desc, (size_t)nframes * cap * 32));
+        HIP_TRY(e, hipMalloc(&e->d_out_cnt, (size_t)nframes * sizeof(int)));
+        e->d_out_frames = nframes; e->d_out_cap = cap;
+    }
+    for (int f = 0; f < nframes; f++)
+        HIP_TRY(e, hipMemcpy2DAsync(e->d_in + f * dev_frame, dev_row, imgs + f * frame_stride, row_stride, width, height,
+                                    hipMemcpyHostToDevice, e->stream));
+    int rc = orbhip_extract_batch_device(e, e->d_in, nframes, width, height, dev_row, dev_frame,
+                                         reinterpret_cast<orbhip_keypoint*>(e->d_out_kp), e->d_out_desc, e->d_out_cnt, cap, nullptr);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(counts, e->d_out_cnt, (size_t)nframes * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    collect_timing(e);
+    rc = check_status(e);
+    if (rc) return rc;
+    for (int f = 0; f < nframes; f++) {
+        const int n = counts[f];
+        if (n <= 0) continue;
+        HIP_TRY(e, hipMemcpyAsync(kp + (size_t)f * cap, e->d_out_kp + (size_t)f * cap * 7, (size_t)n * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(desc + (size_t)f * cap * 32, e->d_out_desc + (size_t)f * cap * 32, (size_t)n * 32, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return ORBHIP_OK;
+}
+
+int orbhip_extract(orbhip_extractor* e, const uint8_t* img, int width, int height, size_t stride,
+                   orbhip_keypoint* kp, int cap, int* n, uint8_t* desc) {
+    if (!e || !n) return ORBHIP_ERR_ARG;
+    int count = 0;
+    int rc = orbhip_extract_batch(e, img, 1, width, height, stride, stride * (size_t)std::max(height, 0), kp, desc, &count, cap);
+    if (rc == ORBHIP_OK) *n = count;
+    return rc;
+}
+
+int orbhip_max_keypoints(const orbhip_extractor* e) {
+    if (!e) return ORBHIP_ERR_ARG;
+    // per level the list stops growing once it reaches its quota; one split adds at most 3 nodes,
+    // and the first round can produce 4 nodes per initial node (at most ~10 initial nodes for any
+    // aspect ratio the tables support)
+    int total = 0;
+    for (int l = 0; l < e->prm.nlevels; l++) total += std::max(e->per_level[l] + 3, 64) + 1;
+    return total;
+}
+
+int orbhip_get_levels(const orbhip_extractor* e) { return e ? e->prm.nlevels : ORBHIP_ERR_ARG; }
+float orbhip_get_scale_factor(const orbhip_extractor* e) { return e ? (float)e->scale_factor_d : 0.f; }
+static int copy_table(const orbhip_extractor* e, const std::vector<float>& t, float* out) {
+    if (!e || !out) return ORBHIP_ERR_ARG;
+    std::memcpy(out, t.data(), t.size() * sizeof(float));
+    return ORBHIP_OK;
+}
+int orbhip_get_scale_factors(const orbhip_extractor* e, float* out) { return e ? copy_table(e, e->sf, out) : ORBHIP_ERR_ARG; }
+int orbhip_get_inverse_scale_factors(const orbhip_extractor* e, float* out) { return e ? copy_table(e, e->inv_sf, out) : ORBHIP_ERR_ARG; }
+int orbhip_get_scale_sigma_squares(const orbhip_extractor* e, float* out) { return e ? copy_table(e, e->sigma2, out) : ORBHIP_ERR_ARG; }
+int orbhip_get_inverse_scale_sigma_squares(const orbhip_extractor* e, float* out) { return e ? copy_table(e, e->inv_sigma2, out) : ORBHIP_ERR_ARG; }
+int orbhip_get_features_per_level(const orbhip_extractor* e, int* out) {
+    if (!e || !out) return ORBHIP_ERR_ARG;
+    std::memcpy(out, e->per_level.data(), e->per_level.size() * sizeof(int));
+    return ORBHIP_OK;
+}
+int orbhip_get_umax(const orbhip_extractor* e, int* out16) {
+    if (!e || !out16) return ORBHIP_ERR_ARG;
+    std::memcpy(out16, e->umax, sizeof(e->umax));
+    return ORBHIP_OK;
+}
+
+int orbhip_pyramid_info(const orbhip_extractor* e, int level, int* width, int* height) {
+    if (!e || !width || !height || level < 0 || level >= e->prm.nlevels) return ORBHIP_ERR_ARG;
+    if (!e->plan_w) return ORBHIP_ERR_STATE;
+    *width = e->plan.lv[level].w;
+    *height = e->plan.lv[level].h;
+    return ORBHIP_OK;
+}
+
+int orbhip_pyramid_copy(orbhip_extractor* e, int frame, int level, uint8_t* dst, size_t dst_stride, int with_border) {
+    if (!e || !dst || level < 0 || level >= e->prm.nlevels) return ORBHIP_ERR_ARG;
+    if (!e->plan_w || frame < 0 || frame >= e->last_pass_frames) return ORBHIP_ERR_STATE;
+    const LevelGeom& g = e->plan.lv[level];
+    const int b = with_border ? ORB_EDGE : 0;
+    if (dst_stride < (size_t)(g.w + 2 * b)) return ORBHIP_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipDeviceSynchronize());
+    const uint8_t* src = e->d_pyr + g.pyr_off + (size_t)frame * g.plane_bytes + (size_t)(ORB_OY - b) * g.pitch + (ORB_OX - b);
+    HIP_TRY(e, hipMemcpy2D(dst, dst_stride, src, g.pitch, g.w + 2 * b, g.h + 2 * b, hipMemcpyDeviceToHost));
+    return ORBHIP_OK;
+}
+
+int orbhip_debug_candidates(orbhip_extractor* e, int frame, int level, orbhip_candidate* out, int cap) {
+    if (!e || level < 0 || level >= e->prm.nlevels) return ORBHIP_ERR_ARG;
+    if (!e->plan_w || frame < 0 || frame >= e->last_pass_frames) return ORBHIP_ERR_STATE;
+    const PlanDev& P = e->plan;
+    const LevelGeom& g = P.lv[level];
+    if (g.ncols < 1) return 0;
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipDeviceSynchronize());
+    int n = 0;
+    HIP_TRY(e, hipMemcpy(&n, e->d_cand_count + frame * P.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    n = std::min(n, g.cand_cap);
+    std::vector<uint2> raw((size_t)std::max(n, 1));
+    std::vector<int> cells((size_t)g.ncols * g.nrows);
+    HIP_TRY(e, hipMemcpy(raw.data(), e->d_cand + (size_t)frame * P.cand_per_frame + g.cand_off, (size_t)n * sizeof(uint2), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(cells.data(), e->d_cell_ini + (size_t)frame * P.cells_per_frame + g.cell_off, cells.size() * sizeof(int), hipMemcpyDeviceToHost));
+    struct Item { unsigned ord; orbhip_candidate c; };
+    std::vector<Item> items;
+    for (int i = 0; i < n; i++) {
+        const int x = raw[i].x & 0xFFFF, y = raw[i].x >> 16, s = raw[i].y & 0xFF;
+        const int cx = (x - 3) / g.wcell, cy = (y - 3) / g.hcell;
+        if (s < P.ini_th && cells[cy * g.ncols + cx] != 0) continue;   // src/ORBextractor.cc:808-816
+        const unsigned ord = (unsigned)(((cy * g.ncols + cx) * g.hcell + (y - 3 - cy * g.hcell)) * g.wcell + (x - 3 - cx * g.wcell));
+        items.push_back(Item{ord, orbhip_candidate{x, y, s}});
+    }
+    std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.ord < b.ord; });
+    for (size_t i = 0; i < items.size() && (int)i < cap; i++) out[i] = items[i].c;
+    return (int)items.size();
+}
+
+int orbhip_enable_timing(orbhip_extractor* e, int on) {
+    if (!e) return ORBHIP_ERR_ARG;
+    e->timing = on != 0;
+    std::memset(e->kc_ms, 0, sizeof(e->kc_ms));
+    std::memset(e->kc_launches, 0, sizeof(e->kc_launches));
+    return ORBHIP_OK;
+}
+
+int orbhip_get_timing(orbhip_extractor* e, const char** names, float* ms, int* launches, int cap) {
+    if (!e) return ORBHIP_ERR_ARG;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    collect_timing(e);
+    for (int i = 0; i < KC_COUNT && i < cap; i++) {
+        if (names) names[i] = kKernelNames[i];
+        if (ms) ms[i] = e->kc_ms[i];
+        if (launches) launches[i] = e->kc_launches[i];
+    }
+    return KC_COUNT;
+}
+
+const char* orbhip_strerror(int code) {
+    switch (code) {
+        case ORBHIP_OK: return "ok";
+        case ORBHIP_ERR_ARG: return "invalid argument";
+        case ORBHIP_ERR_EMPTY: return "empty image";
+        case ORBHIP_ERR_CAPACITY: return "capacity exceeded";
+        case ORBHIP_ERR_GEOMETRY: return "unsupported image geometry";
+        case ORBHIP_ERR_HIP: return "HIP runtime error";
+        case ORBHIP_ERR_NO_DEVICE: return "no usable HIP device";
+        case ORBHIP_ERR_STATE: return "no extraction has run yet";
+        default: return "unknown error";
+    }
+}
+
+const char* orbhip_last_error(const orbhip_extractor* e) { return e ? e->err.c_str() : ""; }
+
+} // extern "C"

@@ -1,0 +1,227 @@
+"""ctypes binding of libORBhip and a host class with the reference's ORBextractor interface.
+
+`ORBextractor` mirrors ORB_SLAM2::ORBextractor (reference include/ORBextractor.h:45-111): same
+constructor arguments, `__call__(image, mask)` for operator(), the six accessors and
+`mvImagePyramid`. Everything is computed by the HIP library; there is no CPU fallback and the
+import fails loudly when the library is missing.
+"""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libORBhip.so"
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+CAND_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("response", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+BLUR_LEGACY, BLUR_FIXEDPOINT = 0, 1
+OK, ERR_ARG, ERR_EMPTY, ERR_CAPACITY, ERR_GEOMETRY, ERR_HIP, ERR_NO_DEVICE, ERR_STATE = 0, -1, -2, -3, -4, -5, -6, -7
+
+# every symbol include/orbhip.h declares
+EXPORTS = [
+    "orbhip_create", "orbhip_destroy", "orbhip_extract", "orbhip_extract_batch_device",
+    "orbhip_extract_batch", "orbhip_synchronize", "orbhip_max_keypoints", "orbhip_get_levels",
+    "orbhip_get_scale_factor", "orbhip_get_scale_factors", "orbhip_get_inverse_scale_factors",
+    "orbhip_get_scale_sigma_squares", "orbhip_get_inverse_scale_sigma_squares",
+    "orbhip_get_features_per_level", "orbhip_get_umax", "orbhip_pyramid_info", "orbhip_pyramid_copy",
+    "orbhip_debug_candidates", "orbhip_enable_timing", "orbhip_get_timing", "orbhip_strerror",
+    "orbhip_last_error",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
+                ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int), ("device", C.c_int),
+                ("blur_variant", C.c_int), ("max_batch", C.c_int)]
+
+
+class OrbHipError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        msg = lib().orbhip_strerror(code).decode()
+        super().__init__("libORBhip: %s (%d)%s" % (msg, code, (": " + detail) if detail else ""))
+
+
+_lib = None
+
+
+def lib():
+    """Loads libORBhip.so from the package directory (build it with visual_slam_amd/build.py)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError("libORBhip.so is missing: run `python -m visual_slam_amd.build` (hipcc, gfx950)")
+        L = C.CDLL(str(LIB_PATH))
+        vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)
+        L.orbhip_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+        L.orbhip_destroy.argtypes = [vp]
+        L.orbhip_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_int, ip, vp]
+        L.orbhip_extract_batch_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
+                                                  vp, vp, vp, C.c_int, vp]
+        L.orbhip_extract_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, vp, vp, vp, C.c_int]
+        L.orbhip_synchronize.argtypes = [vp]
+        L.orbhip_max_keypoints.argtypes = [vp]
+        L.orbhip_get_levels.argtypes = [vp]
+        L.orbhip_get_scale_factor.argtypes = [vp]
+        L.orbhip_get_scale_factor.restype = C.c_float
+        for name in ("orbhip_get_scale_factors", "orbhip_get_inverse_scale_factors",
+                     "orbhip_get_scale_sigma_squares", "orbhip_get_inverse_scale_sigma_squares"):
+            getattr(L, name).argtypes = [vp, fp]
+        L.orbhip_get_features_per_level.argtypes = [vp, ip]
+        L.orbhip_get_umax.argtypes = [vp, ip]
+        L.orbhip_pyramid_info.argtypes = [vp, C.c_int, ip, ip]
+        L.orbhip_pyramid_copy.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t, C.c_int]
+        L.orbhip_debug_candidates.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+        L.orbhip_enable_timing.argtypes = [vp, C.c_int]
+        L.orbhip_get_timing.argtypes = [vp, C.POINTER(C.c_char_p), fp, ip, C.c_int]
+        L.orbhip_strerror.argtypes = [C.c_int]
+        L.orbhip_strerror.restype = C.c_char_p
+        L.orbhip_last_error.argtypes = [vp]
+        L.orbhip_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class ORBextractor:
+    """Drop-in counterpart of ORB_SLAM2::ORBextractor backed by libORBhip."""
+
+    HARRIS_SCORE, FAST_SCORE = 0, 1   # include/ORBextractor.h:49
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device=0,
+                 blur_variant=BLUR_LEGACY, max_batch=0):
+        self._h = C.c_void_p()
+        p = Params(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device, blur_variant, max_batch)
+        rc = lib().orbhip_create(C.byref(p), C.byref(self._h))
+        if rc:
+            self._h = None
+            raise OrbHipError(rc)
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+        self.mvImagePyramid = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().orbhip_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc:
+            raise OrbHipError(rc, lib().orbhip_last_error(self._h).decode())
+
+    # ---- operator() ---------------------------------------------------------------------------
+    def __call__(self, image, mask=None, fetch_pyramid=True):
+        """operator()(image, mask, keypoints, descriptors): returns (keypoints, descriptors).
+
+        An empty image returns (None, None), leaving the caller's previous outputs as they were,
+        like the reference (src/ORBextractor.cc:1046-1047). The mask is ignored, as there.
+        """
+        if image is None or image.size == 0:
+            return None, None
+        image = np.asarray(image)
+        if image.dtype != np.uint8 or image.ndim != 2:
+            raise TypeError("image must be 8-bit single channel (CV_8UC1)")
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)
+        h, w = image.shape
+        cap = self.max_keypoints()
+        kp = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        self._check(lib().orbhip_extract(self._h, _ptr(image), w, h, image.strides[0], _ptr(kp), cap, C.byref(n), _ptr(desc)))
+        if fetch_pyramid:
+            self.mvImagePyramid = [self.pyramid_level(l) for l in range(self.nlevels)]
+        return kp[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch(self, images):
+        """operator() over a (F,H,W) uint8 array of independent frames (host buffers)."""
+        images = np.ascontiguousarray(images, np.uint8)
+        f, h, w = images.shape
+        cap = self.max_keypoints()
+        kp = np.zeros((f, cap), KP_DTYPE)
+        desc = np.zeros((f, cap, 32), np.uint8)
+        counts = np.zeros(f, np.int32)
+        self._check(lib().orbhip_extract_batch(self._h, _ptr(images), f, w, h, images.strides[1], images.strides[0],
+                                               _ptr(kp), _ptr(desc), _ptr(counts), cap))
+        return [(kp[i, :counts[i]].copy(), desc[i, :counts[i]].copy()) for i in range(f)]
+
+    def extract_batch_device(self, d_imgs, nframes, w, h, row_stride, frame_stride, d_kp, d_desc, d_counts, cap, stream=None):
+        """Raw-pointer batch call on device-resident frames; asynchronous on `stream`."""
+        self._check(lib().orbhip_extract_batch_device(self._h, d_imgs, nframes, w, h, row_stride, frame_stride,
+                                                      d_kp, d_desc, d_counts, cap, stream))
+
+    def synchronize(self):
+        self._check(lib().orbhip_synchronize(self._h))
+
+    def max_keypoints(self):
+        return lib().orbhip_max_keypoints(self._h)
+
+    # ---- accessors (include/ORBextractor.h:63-83) ----------------------------------------------
+    def GetLevels(self):
+        return lib().orbhip_get_levels(self._h)
+
+    def GetScaleFactor(self):
+        return lib().orbhip_get_scale_factor(self._h)
+
+    def _table(self, fn):
+        out = np.zeros(self.nlevels, np.float32)
+        self._check(fn(self._h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def GetScaleFactors(self):
+        return self._table(lib().orbhip_get_scale_factors)
+
+    def GetInverseScaleFactors(self):
+        return self._table(lib().orbhip_get_inverse_scale_factors)
+
+    def GetScaleSigmaSquares(self):
+        return self._table(lib().orbhip_get_scale_sigma_squares)
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._table(lib().orbhip_get_inverse_scale_sigma_squares)
+
+    def features_per_level(self):
+        out = np.zeros(self.nlevels, np.int32)
+        self._check(lib().orbhip_get_features_per_level(self._h, out.ctypes.data_as(C.POINTER(C.c_int))))
+        return out
+
+    def umax(self):
+        out = np.zeros(16, np.int32)
+        self._check(lib().orbhip_get_umax(self._h, out.ctypes.data_as(C.POINTER(C.c_int))))
+        return out
+
+    # ---- mvImagePyramid --------------------------------------------------------------------------
+    def pyramid_level(self, level, frame=0, with_border=False):
+        w, h = C.c_int(), C.c_int()
+        self._check(lib().orbhip_pyramid_info(self._h, level, C.byref(w), C.byref(h)))
+        b = 38 if with_border else 0
+        out = np.zeros((h.value + b, w.value + b), np.uint8)
+        self._check(lib().orbhip_pyramid_copy(self._h, frame, level, _ptr(out), out.strides[0], int(with_border)))
+        return out
+
+    # ---- diagnostics ---------------------------------------------------------------------------
+    def debug_candidates(self, level, frame=0):
+        n = lib().orbhip_debug_candidates(self._h, frame, level, None, 0)
+        if n < 0:
+            raise OrbHipError(n)
+        out = np.zeros(max(n, 1), CAND_DTYPE)
+        lib().orbhip_debug_candidates(self._h, frame, level, _ptr(out), n)
+        return out[:n]
+
+    def enable_timing(self, on=True):
+        self._check(lib().orbhip_enable_timing(self._h, int(on)))
+
+    def timing(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        launches = (C.c_int * 16)()
+        n = lib().orbhip_get_timing(self._h, names, ms, launches, 16)
+        return {names[i].decode(): (ms[i], launches[i]) for i in range(n)}
