@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the ORB extraction hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" is one full extraction pass (pyramid, FAST + quadtree, orientation, blur + rBRIEF) over
+a batch of synthetic 1920x1080 frames that already sit in HBM (workload C4: 2000 features,
+8 levels, scale 1.2, FAST 20/7). With N GPUs every rank owns its own batch of the same size (weak
+scaling, frames are independent, no data-path collective); the job value is total frames / max
+rank time. Rank 0 prints one JSON line.
+
+The line also carries
+  roofline     : the kernel class with the largest device time, its algorithmic bytes per launch
+                 divided by its average launch duration (HIP events recorded inside libORBhip on
+                 the stream the kernels run on), against the 8 TB/s HBM3E peak;
+  cpu_baseline : the CPU oracle (a restatement of the reference's CPU extractor) timed on a
+                 bounded sample of the same workload on the host cores of this box.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+
+WORKLOADS = {
+    # name: (w, h, nfeatures, scale, levels, iniTh, minTh)
+    "C4_1080p_2000f": (1920, 1080, 2000, 1.2, 8, 20, 7),
+    "C5_4k_8000f": (3840, 2160, 8000, 1.1, 12, 20, 7),
+    "C1_tum": (640, 480, 1000, 1.2, 8, 20, 7),
+    "C2_kitti": (1241, 376, 2000, 1.2, 8, 20, 7),
+    "C3_euroc": (752, 480, 1200, 1.2, 8, 20, 7),
+}
+
+
+def level_sizes(w, h, scale, levels):
+    """Level sizes exactly as ComputePyramid derives them (float32 scale chain, round half even)."""
+    sf = np.float32(1.0)
+    out = []
+    for l in range(levels):
+        if l:
+            sf = np.float32(np.float64(sf) * np.float64(np.float32(scale)))
+        inv = np.float32(1.0) / sf
+        out.append((int(np.rint(np.float32(w) * inv)), int(np.rint(np.float32(h) * inv))))
+    return out
+
+
+def algorithmic_bytes(w, h, scale, levels, n_out):
+    """Bytes per frame a perfect implementation must move, split by kernel class.
+
+    total = W*H + sum (w_l+38)(h_l+38) + sum_{l<n-1} w_l*h_l + 2*sum w_l*h_l + 60*N_out
+    """
+    lv = level_sizes(w, h, scale, levels)
+    area = [a * b for a, b in lv]
+    bordered = [(a + 38) * (b + 38) for a, b in lv]
+    parts = {
+        "k_level0": w * h + bordered[0],
+        "k_resize": sum(area[:-1]) + sum(bordered[1:]),
+        "k_fast": sum(area),
+        "k_quadtree": 0,
+        "k_describe": sum(area) + 60 * n_out,
+    }
+    return parts, sum(parts.values())
+
+
+def make_batch_on_device(torch, kind, w, h, nframes, device, nbase=16):
+    """nbase host-generated frames, expanded on the device by distinct circular shifts."""
+    from visual_slam_amd import synth
+    nbase = min(nbase, nframes)
+    base = torch.from_numpy(synth.batch(kind, w, h, nbase)).to(device)
+    out = torch.empty((nframes, h, w), dtype=torch.uint8, device=device)
+    for i in range(nframes):
+        b, k = i % nbase, i // nbase
+        out[i] = base[b] if k == 0 else torch.roll(base[b], shifts=(37 * k % h, 101 * k % w), dims=(0, 1))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--max-batch", type=int, default=0, help="frames per internal pass (0 = library default)")
+    ap.add_argument("--workload", default="C4_1080p_2000f", choices=sorted(WORKLOADS))
+    ap.add_argument("--kind", default="blocks", choices=["blocks", "noise", "lowc"])
+    ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--host-fed", action="store_true", help="also time the PCIe-inclusive host-buffer entry point")
+    args = ap.parse_args()
+
+    import torch
+    from visual_slam_amd import orbhip
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (libORBhip has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    w, h, nfeat, scale, levels, ini_th, min_th = WORKLOADS[args.workload]
+    ex = orbhip.ORBextractor(nfeat, scale, levels, ini_th, min_th, device=local_rank, max_batch=args.max_batch)
+    cap = ex.max_keypoints()
+    B = args.batch
+    frames = make_batch_on_device(torch, args.kind, w, h, B, device)
+    d_kp = torch.empty((B, cap, 7), dtype=torch.float32, device=device)
+    d_desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=device)
+    d_cnt = torch.zeros((B,), dtype=torch.int32, device=device)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        ex.extract_batch_device(frames.data_ptr(), B, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(),
+                                d_cnt.data_ptr(), cap, stream.cuda_stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ex.synchronize()   # raises on a deferred capacity error
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    fps = world * B * args.steps / dt
+
+    if rank == 0:
+        counts = d_cnt.cpu().numpy()
+        n_out = float(counts.mean())
+        parts, total_bytes = algorithmic_bytes(w, h, scale, levels, nfeat)
+        # per-kernel device time, HIP events on the launch stream (one extra, untimed step)
+        ex.enable_timing(True)
+        prof_steps = 2
+        for _ in range(prof_steps):
+            step()
+        torch.cuda.synchronize()
+        timing = ex.timing()
+        ex.enable_timing(False)
+        kname = max(timing, key=lambda k: timing[k][0])
+        k_ms, k_launches = timing[kname]
+        k_bytes_per_launch = parts[kname] * B * prof_steps / max(k_launches, 1)
+        k_avg_s = k_ms * 1e-3 / max(k_launches, 1)
+        achieved = k_bytes_per_launch / k_avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_launch": int(k_bytes_per_launch), "avg_launch_ms": round(k_avg_s * 1e3, 4),
+                    "whole_path_bytes_per_frame": int(total_bytes),
+                    "whole_path_frac": round(fps / world * total_bytes / 1e9 / HBM_PEAK_GBS, 4),
+                    "kernel_ms_per_step": {k: round(v[0] / prof_steps, 3) for k, v in timing.items()}}
+        cpu = None
+        if args.cpu_frames > 0:
+            from oracle import orb_oracle   # checker / baseline only, never on the measured GPU path
+            from visual_slam_amd import synth
+            nthreads = min(16, os.cpu_count() or 1)
+            sample = synth.batch(args.kind, w, h, args.cpu_frames)
+            secs, ccounts = orb_oracle.extract_batch_mt((nfeat, scale, levels, ini_th, min_th), sample, nthreads)
+            cpu = {"value": round(args.cpu_frames / secs, 2), "unit": "frames/s", "cores": nthreads, "kind": "port",
+                   "sample": "%d %s frames of %s, one oracle instance per thread" % (args.cpu_frames, args.kind, args.workload)}
+        extra = {}
+        if args.host_fed:
+            host = frames[:min(B, 64)].cpu().numpy()
+            ex.extract_batch(host)
+            t1 = time.perf_counter()
+            ex.extract_batch(host)
+            extra["host_fed_frames_per_s"] = round(len(host) / (time.perf_counter() - t1), 1)
+        line = {
+            "metric": "ORB extract frames/s (1080p, 2k feats)" if args.workload == "C4_1080p_2000f" else "ORB extract frames/s",
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": args.workload, "image": [w, h], "nfeatures": nfeat, "levels": levels, "scale": scale,
+                       "fast_th": [ini_th, min_th], "frames_per_gpu_per_step": B, "distribution": args.kind,
+                       "inputs": "device-resident", "pyramid_copied_back": False, "blur_variant": "legacy",
+                       "mean_keypoints_per_frame": round(n_out, 1), "sharding": "frames, no collective"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

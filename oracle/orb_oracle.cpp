@@ -701,6 +701,26 @@ void orbo_gaussian_blur7(const uint8_t* src, int w, int h, size_t sstride, uint8
 }
 float orbo_fast_atan2(float y, float x) { return fast_atan2(y, x); }
 
+static Plane plane_from(const uint8_t* img, int w, int h, size_t stride) {
+    Plane P;
+    P.create(w, h, 0);
+    for (int y = 0; y < h; y++) std::memcpy(P.px() + (size_t)y * P.step, img + (size_t)y * stride, (size_t)w);
+    return P;
+}
+float orbo_ic_angle(const uint8_t* img, int w, int h, size_t stride, int x, int y) {
+    orbo_extractor* e = orbo_create(100, 1.2f, 1, 20, 7, 0, 0, 0);
+    Plane P = plane_from(img, w, h, stride);
+    float a = ic_angle(P, (float)x, (float)y, e->umax);
+    orbo_destroy(e);
+    return a;
+}
+void orbo_descriptor(const uint8_t* img, int w, int h, size_t stride, int x, int y, float angle_deg,
+                     int fma_mode, uint8_t* out32) {
+    Plane P = plane_from(img, w, h, stride);
+    orbo_keypoint kp{(float)x, (float)y, 31.f, angle_deg, 0.f, 0, -1};
+    orb_descriptor(kp, P, fma_mode, out32);
+}
+
 int orbo_distribute(const orbo_candidate* cand, int ncand, int min_x, int max_x, int min_y, int max_y,
                     int n_wanted, int tie_mode, orbo_candidate* out, int cap) {
     std::vector<Key> keys(ncand), kept;

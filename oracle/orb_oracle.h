@@ -79,6 +79,12 @@ int orbo_fast9(const uint8_t* img, int w, int h, size_t stride, int threshold,
 void orbo_gaussian_blur7(const uint8_t* src, int w, int h, size_t sstride,
                          uint8_t* dst, size_t dstride, int blur_variant);
 float orbo_fast_atan2(float y, float x);
+/* IC_Angle at (x, y) of a plain image; the 15-px disc must lie inside the image. */
+float orbo_ic_angle(const uint8_t* img, int w, int h, size_t stride, int x, int y);
+/* computeOrbDescriptor at (x, y) with the given angle (degrees) on an (already blurred) image;
+ * the 19-px reach must lie inside the image. */
+void orbo_descriptor(const uint8_t* img, int w, int h, size_t stride, int x, int y, float angle_deg,
+                     int fma_mode, uint8_t* out32);
 /* DistributeOctTree on a hand-built candidate set (coords relative to minX/minY). Returns count. */
 int orbo_distribute(const orbo_candidate* cand, int ncand, int min_x, int max_x, int min_y, int max_y,
                     int n_wanted, int tie_mode, orbo_candidate* out, int cap);

@@ -63,6 +63,9 @@ def lib():
         L.orbo_gaussian_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
         L.orbo_fast_atan2.restype = C.c_float
         L.orbo_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orbo_ic_angle.restype = C.c_float
+        L.orbo_ic_angle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int]
+        L.orbo_descriptor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.orbo_distribute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.orbo_extract_batch_mt.restype = C.c_double
         L.orbo_extract_batch_mt.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -183,6 +186,18 @@ def gaussian_blur7(img, variant=BLUR_LEGACY):
 
 def fast_atan2(y, x):
     return lib().orbo_fast_atan2(float(y), float(x))
+
+
+def ic_angle(img, x, y):
+    img = np.ascontiguousarray(img, np.uint8)
+    return lib().orbo_ic_angle(_ptr(img), img.shape[1], img.shape[0], img.strides[0], x, y)
+
+
+def descriptor(img, x, y, angle_deg, fma_mode=FMA_OFF):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros(32, np.uint8)
+    lib().orbo_descriptor(_ptr(img), img.shape[1], img.shape[0], img.strides[0], x, y, angle_deg, fma_mode, _ptr(out))
+    return out
 
 
 def distribute(cands, min_x, max_x, min_y, max_y, n_wanted, tie_mode=TIE_CREATION_ORDER):
