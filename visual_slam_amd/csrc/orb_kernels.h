@@ -3,7 +3,7 @@
 // Pipeline per pass over F frames (all frames of a pass share one launch, blockIdx.z/y = frame):
 //   k_level0     input image -> level 0 plane with REFLECT_101 border     (src/ORBextractor.cc:1127-1128)
 //   k_resize     level l-1 -> level l, cv::resize 8U INTER_LINEAR + border (src/ORBextractor.cc:1120-1123)
-//   k_fast       FAST-9 score, per-cell NMS, per-cell iniTh count, append  (src/ORBextractor.cc:789-829)
+//   k_fast       FAST-9 score, per-cell NMS, per-cell iniTh count, append  (orb_fast.h; src/ORBextractor.cc:789-829)
 //   k_quadtree   DistributeOctTree, one workgroup per (level, frame)       (src/ORBextractor.cc:539-763)
 //   k_describe   IC_Angle + 7x7 blur of the 45x45 patch + rBRIEF, one wave per keypoint
 //                                                                          (src/ORBextractor.cc:77-147,1085-1101)
@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "orb_device.h"
+#include "orb_fast.h"
 
 __device__ __forceinline__ int reflect101(int p, int len) {
     if (len == 1) return 0;
@@ -63,146 +64,6 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, Level
     }
     uint8_t* D = pyr + gd.pyr_off + (size_t)f * gd.plane_bytes + (size_t)r * gd.pitch;
     reinterpret_cast<uint32_t*>(D)[c4] = out;
-}
-
-// ------------------------------------------------------------------------------------------------
-// FAST-9/16 corner score. S = (largest t such that the pixel is a FAST-9 corner at threshold t),
-// i.e. max over the 16 nine-pixel arcs of min |centre - ring| over the arc (same sign over the arc)
-// minus 1. A pixel is a corner at threshold t iff S >= t, and cv::FAST's cornerScore equals S for
-// every corner, whatever threshold it was detected with.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int fast_score16(int v, const int p[16]) {
-    int d[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = v - p[k];
-    // arcs [k..k+8] and [k+1..k+9] for even k share d[k+1..k+8]
-    int lo2[8], hi2[8];   // min/max of d[i], d[i+1] for odd i = 2j+1
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int i = 2 * j + 1;
-        lo2[j] = min(d[i & 15], d[(i + 1) & 15]);
-        hi2[j] = max(d[i & 15], d[(i + 1) & 15]);
-    }
-    int lo4[8], hi4[8];   // over d[i..i+3]
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        lo4[j] = min(lo2[j], lo2[(j + 1) & 7]);
-        hi4[j] = max(hi2[j], hi2[(j + 1) & 7]);
-    }
-    int a0 = -256, b0 = 256;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {   // k = 2j: inner eight are d[k+1..k+8]
-        const int k = 2 * j;
-        const int lo8 = min(lo4[j], lo4[(j + 2) & 7]);
-        const int hi8 = max(hi4[j], hi4[(j + 2) & 7]);
-        a0 = max(a0, min(lo8, max(d[k], d[(k + 9) & 15])));
-        b0 = min(b0, max(hi8, min(d[k], d[(k + 9) & 15])));
-    }
-    return max(a0, -b0) - 1;
-}
-
-#define FAST_TW 64
-#define FAST_TH 16
-#define FAST_IW (FAST_TW + 8)      // image tile with a 4-px halo
-#define FAST_IH (FAST_TH + 8)
-#define FAST_IP 76                 // image tile row pitch in LDS
-#define FAST_SW (FAST_TW + 2)      // score tile with a 1-px apron
-#define FAST_SH (FAST_TH + 2)
-#define FAST_SP 68
-#define FAST_STAGE 1024
-
-// One workgroup scores a 64x16 tile of the detectable area [19,w-19)x[19,h-19) of one level.
-// Non-maximum suppression and the threshold choice are per ~30-px cell in the reference (each cell
-// is a separate cv::FAST call): a corner survives iff its score is strictly above every 8-neighbour
-// that lies in the same cell, and it is emitted if score >= iniTh, or if its cell has no
-// survivor >= iniTh (decided later from cell_ini, by the consumer of the candidate list).
-__global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, LevelGeom g, int level,
-                                              int nlevels, int ini_th, int min_th, int cells_per_frame,
-                                              unsigned long long cand_per_frame,
-                                              uint2* __restrict__ cand, int* __restrict__ cand_count,
-                                              int* __restrict__ cell_ini, int* __restrict__ status) {
-    __shared__ uint8_t s_img[FAST_IH * FAST_IP];
-    __shared__ uint8_t s_sc[FAST_SH * FAST_SP];
-    __shared__ uint2 s_stage[FAST_STAGE];
-    __shared__ int s_n, s_base;
-    const int tid = threadIdx.x;
-    const int f = blockIdx.z;
-    const int tx0 = ORB_EDGE + blockIdx.x * FAST_TW;   // level coords of the tile's first pixel
-    const int ty0 = ORB_EDGE + blockIdx.y * FAST_TH;
-    const uint8_t* P = pyr + g.pyr_off + (size_t)f * g.plane_bytes;
-    if (tid == 0) s_n = 0;
-    for (int i = tid; i < FAST_IH * (FAST_IW / 4); i += 256) {
-        const int ry = i / (FAST_IW / 4), rx4 = i % (FAST_IW / 4);
-        const int row = ty0 - 4 + ry + ORB_OY;
-        const int col = tx0 - 4 + rx4 * 4 + ORB_OX;   // tx0-4+ORB_OX = 47 + 64*bx: not dword aligned
-        uint32_t v = 0;
-        if (row < g.rows) {
-            const uint8_t* R = P + (size_t)row * g.pitch;
-#pragma unroll
-            for (int b = 0; b < 4; b++)
-                if (col + b < g.pitch) v |= (uint32_t)R[col + b] << (8 * b);
-        }
-        *reinterpret_cast<uint32_t*>(&s_img[ry * FAST_IP + rx4 * 4]) = v;
-    }
-    __syncthreads();
-    const int x_hi = g.w - ORB_EDGE, y_hi = g.h - ORB_EDGE;
-    for (int i = tid; i < FAST_SW * FAST_SH; i += 256) {
-        const int sy = i / FAST_SW, sx = i % FAST_SW;
-        const int x = tx0 - 1 + sx, y = ty0 - 1 + sy;
-        int s = 0;
-        if (x >= ORB_EDGE && x < x_hi && y >= ORB_EDGE && y < y_hi) {
-            const uint8_t* c = &s_img[(sy + 3) * FAST_IP + sx + 3];
-            int p[16];
-            p[0] = c[3 * FAST_IP];       p[1] = c[3 * FAST_IP + 1];   p[2] = c[2 * FAST_IP + 2];   p[3] = c[FAST_IP + 3];
-            p[4] = c[3];                 p[5] = c[-FAST_IP + 3];      p[6] = c[-2 * FAST_IP + 2];  p[7] = c[-3 * FAST_IP + 1];
-            p[8] = c[-3 * FAST_IP];      p[9] = c[-3 * FAST_IP - 1];  p[10] = c[-2 * FAST_IP - 2]; p[11] = c[-FAST_IP - 3];
-            p[12] = c[-3];               p[13] = c[FAST_IP - 3];      p[14] = c[2 * FAST_IP - 2];  p[15] = c[3 * FAST_IP - 1];
-            s = fast_score16(c[0], p);
-            if (s < min_th) s = 0;
-        }
-        s_sc[sy * FAST_SP + sx] = (uint8_t)s;
-    }
-    __syncthreads();
-    for (int i = tid; i < FAST_TW * FAST_TH; i += 256) {
-        const int iy = i / FAST_TW, ix = i % FAST_TW;
-        const uint8_t* c = &s_sc[(iy + 1) * FAST_SP + ix + 1];
-        const int s = c[0];
-        if (s == 0) continue;
-        const int x = tx0 + ix, y = ty0 + iy;
-        const int ux = x - ORB_EDGE, uy = y - ORB_EDGE;
-        const int cx = ux / g.wcell, cy = uy / g.hcell;
-        const int xin = ux - cx * g.wcell, yin = uy - cy * g.hcell;
-        // neighbours outside the detectable area already score 0
-        const bool l = xin > 0, r = xin < g.wcell - 1, u = yin > 0, d = yin < g.hcell - 1;
-        bool keep = true;
-        if (l) keep = keep && s > c[-1];
-        if (r) keep = keep && s > c[1];
-        if (u) {
-            keep = keep && s > c[-FAST_SP];
-            if (l) keep = keep && s > c[-FAST_SP - 1];
-            if (r) keep = keep && s > c[-FAST_SP + 1];
-        }
-        if (d) {
-            keep = keep && s > c[FAST_SP];
-            if (l) keep = keep && s > c[FAST_SP - 1];
-            if (r) keep = keep && s > c[FAST_SP + 1];
-        }
-        if (!keep) continue;
-        if (s >= ini_th) atomicAdd(&cell_ini[(size_t)f * cells_per_frame + g.cell_off + cy * g.ncols + cx], 1);
-        const int slot = atomicAdd(&s_n, 1);
-        if (slot < FAST_STAGE) s_stage[slot] = make_uint2((uint32_t)(x - ORB_MINB) | ((uint32_t)(y - ORB_MINB) << 16), (uint32_t)s);
-    }
-    __syncthreads();
-    const int n = min(s_n, FAST_STAGE);
-    if (n == 0) return;
-    if (tid == 0) s_base = atomicAdd(&cand_count[f * nlevels + level], n);
-    __syncthreads();
-    const int base = s_base;
-    uint2* out = cand + (size_t)f * cand_per_frame + g.cand_off;
-    for (int i = tid; i < n; i += 256) {
-        if (base + i < g.cand_cap) out[base + i] = s_stage[i];
-        else atomicOr(status, 1);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -254,8 +254,9 @@ int run_pass(orbhip_extractor* e, hipStream_t s, const uint8_t* d_imgs, int fram
         const int dw = g.w - 2 * ORB_EDGE, dh = g.h - 2 * ORB_EDGE;
         if (dw < 1 || dh < 1) continue;
         SpanGuard t(e, s, KC_FAST);
-        hipLaunchKernelGGL(k_fast, dim3((dw + FAST_TW - 1) / FAST_TW, (dh + FAST_TH - 1) / FAST_TH, frames), dim3(256), 0, s,
-                           e->d_pyr, g, l, nl, P.ini_th, P.min_th, P.cells_per_frame, P.cand_per_frame,
+        const int nstrips = (g.w - ORB_EDGE - ORB_MINB + F2_COLS - 1) / F2_COLS, nbands = (dh + F2_RB - 1) / F2_RB;
+        hipLaunchKernelGGL(k_fast, dim3(nstrips, (nbands + 3) / 4, frames), dim3(256), 0, s,
+                           e->d_pyr, g, l, nl, P.ini_th, P.min_th, P.cells_per_frame, P.cand_per_frame, nbands,
                            e->d_cand, e->d_cand_count, e->d_cell_ini, e->d_status);
     }
     {
