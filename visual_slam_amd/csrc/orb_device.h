@@ -6,6 +6,10 @@
 // occupies columns ORB_OX-19 .. ORB_OX-1 and ORB_OX+w .. ORB_OX+w+18. ORB_OX = 32 keeps the first
 // interior pixel 16-byte aligned; pitch is a multiple of 64. Planes are stored level-major:
 // plane(level, frame) = pyr + lv.pyr_off + frame * lv.plane_bytes.
+//
+// FAST corners travel in two stages. k_fast writes them into fixed output segments, one per
+// (tile, wave), with a count per segment (no atomics, any order). k_quadtree gathers the segments
+// of its level into a compact key array and works on that.
 #pragma once
 #include <stdint.h>
 
@@ -29,10 +33,14 @@ struct LevelGeom {
     // FAST cell grid (src/ORBextractor.cc:773-787)
     int maxbx, maxby;         // maxBorderX/Y = w-16, h-16
     int ncols, nrows, wcell, hcell;
-    int cell_off;             // first cell of this level in the per-frame cell counter array
-    // candidates
-    int cand_cap;             // capacity of the candidate list of this level
-    unsigned long long cand_off;     // entry offset inside a frame's candidate block
+    unsigned wcell_magic, hcell_magic;   // floor(2^32/d)+1: n/d == umulhi(n, magic) for n < 65536, 1 < d < 65536
+    // FAST output segments
+    int ntx, nty;             // tiles of k_fast in x and y; 4 segments per tile
+    unsigned long long seg_off;      // entry offset of this level's first segment inside a frame's segment block
+    int segc_off;             // offset of this level's first segment count inside a frame's count block
+    // compact keys of the quadtree
+    int keys_cap;             // capacity of the compact key array of this level
+    unsigned long long keys_off;     // entry offset inside a frame's key block
     // quadtree (src/ORBextractor.cc:539-563)
     int n_ini; float hx;      // nIni, hX
     int quota;                // mnFeaturesPerLevel[level]
@@ -48,11 +56,12 @@ struct LevelGeom {
 struct PlanDev {
     int nlevels;
     int ini_th, min_th;
-    int cells_per_frame;             // sum over levels of ncols*nrows
-    unsigned long long cand_per_frame;   // sum over levels of cand_cap
-    int kp_per_frame;                // sum over levels of node_cap
-    int blur_taps[4];                // centre, +-1, +-2, +-3
-    int blur_ties_even;              // 1: legacy x86 column kernel (ties to even for x < (w & ~3))
+    unsigned long long seg_per_frame;    // entries of all segments of one frame
+    int segc_per_frame;                  // segments of one frame
+    unsigned long long keys_per_frame;   // sum over levels of keys_cap
+    int kp_per_frame;                    // sum over levels of node_cap
+    int blur_taps[4];                    // centre, +-1, +-2, +-3
+    int blur_ties_even;                  // 1: legacy x86 column kernel (ties to even for x < (w & ~3))
     int umax[16];
     LevelGeom lv[ORB_MAX_LEVELS];
 };

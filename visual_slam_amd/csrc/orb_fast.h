@@ -1,12 +1,5 @@
-// FAST-9/16 corner detection for one pyramid level, streaming form (src/ORBextractor.cc:789-829 and
+// FAST-9/16 corner detection for one pyramid level (src/ORBextractor.cc:789-829 and
 // cv::FAST(img, kps, threshold, true) behind it).
-//
-// A wave owns a strip of 62 four-pixel groups (248 output columns; lanes 0 and 63 only supply
-// score neighbours) and walks down a band of 64 rows. Each lane keeps a 7-row x 12-byte window of
-// the image in registers (one 12-byte load per lane per row), forms the 16 ring differences of two
-// horizontally adjacent pixels at a time as packed 16-bit lanes (v_perm_b32 + v_pk_sub_i16) and
-// evaluates the corner score with a packed min/max network (v_pk_min_i16 / v_pk_max_i16). No LDS is
-// used for the image; LDS only stages the sparse output of a wave.
 //
 // Score S(p) = max over the 16 nine-pixel arcs of min(centre - ring) (centre brighter) or
 // min(ring - centre) (centre darker), minus 1. p is a FAST-9 corner at threshold t iff S(p) >= t and
@@ -15,11 +8,28 @@
 // at minThFAST. Because S does not depend on t this is equivalent to: p survives iff
 // S(p) >= minTh and S(p) is strictly greater than the S of its 8-neighbours inside the same cell;
 // a survivor is used iff S(p) >= iniTh or its cell has no survivor with S >= iniTh. This kernel
-// emits all survivors and counts the survivors >= iniTh per cell; the quadtree kernel applies the
-// last rule when it reads the list.
+// emits all survivors; the quadtree kernel applies the last rule when it gathers them.
+//
+// Work split. A workgroup (4 waves) owns a tile of 248 columns x 32 rows of the detectable area.
+// Scores are needed for tile rows -1..32 (34 rows); the waves sieve 9, 9, 8 and 8 of them.
+//   sieve  (dense)  : every lane holds 4 adjacent pixels. A corner at threshold t needs, for each
+//                     of the opposite ring pairs (N,S) and (E,W), one member that differs from the
+//                     centre by more than t with the same sign. Two pixels at a time are tested
+//                     with packed 16-bit ops (v_perm_b32, v_pk_sub/min/max_i16) straight from
+//                     registers: the rows of a five-row step are loaded together (11 loads
+//                     in flight per lane), the step is fully unrolled, no shuffles. Straight
+//                     edges fail this test; the survivors of a step are compacted into a
+//                     per-wave queue with one wave prefix sum. The loaded rows are also copied
+//                     into an image tile in LDS.
+//   score  (sparse) : queued pixels are taken 64 at a time, one per lane: 16 ring bytes from
+//                     the LDS image tile, exact score, written to a byte map of the tile in LDS.
+//   nms    (sparse) : after a barrier every wave scans its 8 map rows, compacts the non-zero
+//                     scores the same way and handles them one per lane: non-maximum suppression
+//                     inside the cell, then a plain store into the wave's own output segment
+//                     (no atomics, no ordering between waves: the consumer does not depend on
+//                     the order of the candidates).
 #pragma once
 #include <hip/hip_runtime.h>
-#include <utility>
 #include "orb_device.h"
 
 typedef short v2s __attribute__((ext_vector_type(2)));
@@ -29,211 +39,259 @@ __device__ __forceinline__ uint32_t v2u(v2s v) { return __builtin_bit_cast(uint3
 __device__ __forceinline__ v2s pmin(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ v2s pmax(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
 
-// Bresenham circle of radius 3, in cv::FAST's order.
-constexpr int kRingDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
-constexpr int kRingDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
-
-// Bytes O and O+1 of a 12-byte window row, zero-extended into the two halves of a dword.
+// Bytes O and O+1 of the 8-byte string {hi:lo}, zero-extended into the two halves of a dword.
 template <int O>
-__device__ __forceinline__ v2s pick2(const uint32_t (&row)[3]) {
-    static_assert(O >= 0 && O + 1 <= 11, "window offset");
-    if constexpr (O + 1 <= 7) {
-        constexpr uint32_t sel = (uint32_t)O | (0x0Cu << 8) | ((uint32_t)(O + 1) << 16) | (0x0Cu << 24);
-        return u2v(__builtin_amdgcn_perm(row[1], row[0], sel));
-    } else {
-        constexpr uint32_t sel = (uint32_t)(O - 4) | (0x0Cu << 8) | ((uint32_t)(O - 3) << 16) | (0x0Cu << 24);
-        return u2v(__builtin_amdgcn_perm(row[2], row[1], sel));
-    }
+__device__ __forceinline__ v2s pick2(uint32_t hi, uint32_t lo) {
+    static_assert(O >= 0 && O + 1 <= 7, "byte offset");
+    constexpr uint32_t sel = (uint32_t)O | (0x0Cu << 8) | ((uint32_t)(O + 1) << 16) | (0x0Cu << 24);
+    return u2v(__builtin_amdgcn_perm(hi, lo, sel));
 }
 
-// d[k] = centre - ring[k] for the pixel pair PAIR (pixels 2*PAIR, 2*PAIR+1 of the lane's group).
-template <int PAIR, size_t... K>
-__device__ __forceinline__ void ring_diffs(const uint32_t (&W)[7][3], v2s (&d)[16], std::index_sequence<K...>) {
-    const v2s c = pick2<4 + 2 * PAIR>(W[3]);
-    ((d[K] = c - pick2<4 + 2 * PAIR + kRingDX[K]>(W[3 + kRingDY[K]])), ...);
-}
-
-// Necessary condition for a corner at threshold t: every 9-arc contains one pixel of each opposite
-// pair, so all 8 pairs need a member with d > t (centre brighter) or all need one with d < -t.
-// Returns, per half, max(min_j max(d_j,d_j+8), -max_j min(d_j,d_j+8)): the pixel can only be a
-// corner at t if that value is > t.
-__device__ __forceinline__ v2s fast_pretest(const v2s (&d)[16]) {
-    v2s lo = pmax(d[0], d[8]), hi = pmin(d[0], d[8]);
+// Exact corner score of one pixel from its centre value and the 16 ring values (cv::FAST order).
+__device__ __forceinline__ int fast_score16(int v, const int (&p)[16]) {
+    int d[16];
 #pragma unroll
-    for (int j = 1; j < 8; j++) {
-        lo = pmin(lo, pmax(d[j], d[j + 8]));
-        hi = pmax(hi, pmin(d[j], d[j + 8]));
-    }
-    const v2s zero = {0, 0};
-    return pmax(lo, zero - hi);
-}
-
-__device__ __forceinline__ v2s fast_score_packed(const v2s (&d)[16]) {
-    v2s lo2[8], hi2[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {      // d[i], d[i+1] for odd i = 2j+1
-        lo2[j] = pmin(d[(2 * j + 1) & 15], d[(2 * j + 2) & 15]);
-        hi2[j] = pmax(d[(2 * j + 1) & 15], d[(2 * j + 2) & 15]);
-    }
-    v2s lo4[8], hi4[8];
+    for (int k = 0; k < 16; k++) d[k] = v - p[k];
+    int lo2[8], hi2[8];   // min/max of d[i], d[i+1] for odd i = 2j+1
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        lo4[j] = pmin(lo2[j], lo2[(j + 1) & 7]);
-        hi4[j] = pmax(hi2[j], hi2[(j + 1) & 7]);
+        lo2[j] = min(d[(2 * j + 1) & 15], d[(2 * j + 2) & 15]);
+        hi2[j] = max(d[(2 * j + 1) & 15], d[(2 * j + 2) & 15]);
     }
-    v2s a0 = {-256, -256}, b0 = {256, 256};
+    int lo4[8], hi4[8];   // over d[i..i+3]
 #pragma unroll
-    for (int j = 0; j < 8; j++) {      // arcs [k..k+8] and [k+1..k+9], k = 2j, share d[k+1..k+8]
-        const int k = 2 * j;
-        const v2s lo8 = pmin(lo4[j], lo4[(j + 2) & 7]);
-        const v2s hi8 = pmax(hi4[j], hi4[(j + 2) & 7]);
-        a0 = pmax(a0, pmin(lo8, pmax(d[k], d[(k + 9) & 15])));
-        b0 = pmin(b0, pmax(hi8, pmin(d[k], d[(k + 9) & 15])));
+    for (int j = 0; j < 8; j++) {
+        lo4[j] = min(lo2[j], lo2[(j + 1) & 7]);
+        hi4[j] = max(hi2[j], hi2[(j + 1) & 7]);
     }
-    const v2s zero = {0, 0}, one = {1, 1};
-    return pmax(a0, zero - b0) - one;
+    int a0 = -256, b0 = 256;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {   // arcs [k..k+8] and [k+1..k+9], k = 2j, share d[k+1..k+8]
+        const int k = 2 * j;
+        const int lo8 = min(lo4[j], lo4[(j + 2) & 7]);
+        const int hi8 = max(hi4[j], hi4[(j + 2) & 7]);
+        a0 = max(a0, min(lo8, max(d[k], d[(k + 9) & 15])));
+        b0 = min(b0, max(hi8, min(d[k], d[(k + 9) & 15])));
+    }
+    return max(a0, -b0) - 1;
 }
 
-#define F2_RB 64          // rows per band (one wave)
-#define F2_COLS 248       // output columns per strip
-#define F2_STAGE 512      // staged candidates per wave before a flush
+#define FT_COLS 248        // output columns per tile (62 lanes x 4; lanes 0 and 63 are halo)
+#define FT_ROWS 32         // rows per tile
+#define FT_GROUP 5         // rows per unrolled sieve step
+#define FT_P 256           // LDS row pitch of map and image tile (tile column xl <-> level x xs - 4 + xl)
+#define FT_MAP_ROWS 34     // tile rows -1 .. 32
+#define FT_IMG_ROWS 40     // tile rows -4 .. 35
+#define FT_QUEUE 256       // compaction window per wave
+#define FT_SEGCAP 768      // output segment of one wave: 8 rows x 248 columns after NMS hold < 700 survivors
 
 struct __attribute__((packed, aligned(4))) Row12 { uint32_t a, b, c; };
 
-__device__ __forceinline__ void fast_flush(uint2* stage, int n, uint2* out, int* counter, int cap, int* status, int lane) {
-    if (n == 0) return;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(counter, n);
-    base = __shfl(base, 0, 64);
-    for (int i = lane; i < n; i += 64) {
-        if (base + i < cap) out[base + i] = stage[i];
-        else atomicOr(status, 1);
+// Inclusive prefix sum over the 64 lanes with DPP row shifts and row broadcasts.
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2,3
+    return v;
+}
+
+// Every lane holds a bit set (bit b = row b/4 of the block, pixel b%4 of the lane's group). The
+// set bits of the wave are numbered lane by lane; those numbered base .. base+FT_QUEUE-1 are
+// written to the queue as  xl | (row0 + b/4) << 8.
+__device__ __forceinline__ void fast_fill_queue(uint32_t bits, int first, int base, int lane, int row0, uint16_t* queue) {
+    int idx = first - base;
+    while (bits) {
+        const int b = __ffs(bits) - 1;
+        bits &= bits - 1;
+        if (idx >= 0 && idx < FT_QUEUE) queue[idx] = (uint16_t)((4 * lane + (b & 3)) | ((row0 + (b >> 2)) << 8));
+        idx++;
     }
 }
 
-__global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, LevelGeom g, int level,
-                                              int nlevels, int ini_th, int min_th, int cells_per_frame,
-                                              unsigned long long cand_per_frame, int nbands,
-                                              uint2* __restrict__ cand, int* __restrict__ cand_count,
-                                              int* __restrict__ cell_ini, int* __restrict__ status) {
-    __shared__ uint2 s_stage[4][F2_STAGE];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int band = blockIdx.y * 4 + wv;
-    const int f = blockIdx.z;
-    if (band >= nbands) return;                      // the kernel has no workgroup barrier
-    const int xg = ORB_MINB + F2_COLS * (int)blockIdx.x - 4 + 4 * lane;   // level x of this lane's pixel 0
-    const int col = ORB_OX + xg;                     // device column, multiple of 4
-    const bool col_ok = col + 8 <= g.pitch;          // the lane's 12-byte window [col-4, col+8) exists
-    const int yb = ORB_EDGE + F2_RB * band;          // first row of the band
-    const int x_hi = g.w - ORB_EDGE, y_hi = g.h - ORB_EDGE;
-    const uint8_t* P = pyr + g.pyr_off + (size_t)f * g.plane_bytes + (size_t)ORB_OY * g.pitch + (col - 4);
-    uint2* stage = s_stage[wv];
-    uint2* out = cand + (size_t)f * cand_per_frame + g.cand_off;
-    int* counter = cand_count + f * nlevels + level;
-    int* cells = cell_ini + (size_t)f * cells_per_frame + g.cell_off;
+// Scores `n` (<= 64) queued pixels, one per lane, from the LDS image tile into the tile map.
+// Queue entry: xl | map_row << 8; image tile row = map row + 3.
+__device__ __forceinline__ void fast_score_queue(const uint16_t* queue, int n, int lane, const uint8_t* img,
+                                                 int min_th, uint8_t* map) {
+    if (lane < n) {
+        const int e = queue[lane];
+        const int xl = e & 0xFF, row = e >> 8;
+        const uint8_t* c = img + (row + 3) * FT_P + xl;
+        int p[16];
+        p[0] = c[3 * FT_P];      p[1] = c[3 * FT_P + 1];   p[2] = c[2 * FT_P + 2];   p[3] = c[FT_P + 3];
+        p[4] = c[3];             p[5] = c[-FT_P + 3];      p[6] = c[-2 * FT_P + 2];  p[7] = c[-3 * FT_P + 1];
+        p[8] = c[-3 * FT_P];     p[9] = c[-3 * FT_P - 1];  p[10] = c[-2 * FT_P - 2]; p[11] = c[-FT_P - 3];
+        p[12] = c[-3];           p[13] = c[FT_P - 3];      p[14] = c[2 * FT_P - 2];  p[15] = c[3 * FT_P - 1];
+        const int s = fast_score16(c[0], p);
+        if (s >= min_th) map[row * FT_P + xl] = (uint8_t)s;
+    }
+}
 
-    // per-pixel constants of this lane's four columns
-    // bit i: pixel i lies in the detectable area / has a same-cell left / right neighbour
-    uint32_t ok_bits = 0, left_bits = 0, right_bits = 0;
-    const bool emit = lane >= 1 && lane <= 62;       // lanes 0 and 63 only provide neighbour scores
-    int cellx[4];
+// Grid: (tiles in x, tiles in y, frames). Output: segment (tile, wave) of FT_SEGCAP entries
+// {x | y << 16 (relative to the detection window origin (16,16)), score} and its entry count.
+__global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, LevelGeom g, int min_th,
+                                              unsigned long long seg_per_frame, int segc_per_frame,
+                                              uint2* __restrict__ seg, int* __restrict__ seg_count,
+                                              int* __restrict__ status) {
+    __shared__ __align__(16) uint8_t s_map[FT_MAP_ROWS * FT_P];
+    __shared__ __align__(16) uint8_t s_img[FT_IMG_ROWS * FT_P];
+    __shared__ uint16_t s_queue[4][FT_QUEUE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int f = blockIdx.z;
+    const int xs = ORB_MINB + FT_COLS * (int)blockIdx.x;       // level x of the tile's first output column
+    const int y0 = ORB_EDGE + FT_ROWS * (int)blockIdx.y;       // level y of the tile's first row
+    const int x_hi = g.w - ORB_EDGE, y_hi = g.h - ORB_EDGE;    // detectable area [19, x_hi) x [19, y_hi)
+    const int xg = xs - 4 + 4 * lane;                          // level x of this lane's pixel 0
+    const int col = ORB_OX + xg;                               // device column, multiple of 4
+    const bool col_ok = col + 8 <= g.pitch;                    // the lane's 12-byte window [col-4, col+8) exists
+    const uint8_t* plane = pyr + g.pyr_off + (size_t)f * g.plane_bytes;
+    // map row m <-> level row y0 - 1 + m; image tile row t <-> level row y0 - 4 + t
+
+    for (int i = tid; i < FT_MAP_ROWS * FT_P / 16; i += 256) reinterpret_cast<uint4*>(s_map)[i] = make_uint4(0, 0, 0, 0);
+
+    // ---- sieve: map rows m0 .. m0+nrows-1 of this wave (9, 9, 8, 8 rows), five rows per step
+    const int m0 = wv < 2 ? 9 * wv : 2 + 8 * wv;
+    const int nrows = wv < 2 ? 9 : 8;
+    // bit i: pixel i is scored: inside the detectable columns and, for the halo lanes, only the
+    // one column that neighbours an output column (tile columns 3 and 252)
+    uint32_t ok_bits = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int x = xg + i;
-        const bool ok = x >= ORB_EDGE && x < x_hi;
-        const int ux = ok ? x - ORB_EDGE : 0;
-        const int cx = ux / g.wcell;
-        const int xin = ux - cx * g.wcell;
-        cellx[i] = cx;
-        ok_bits |= (uint32_t)ok << i;
-        left_bits |= (uint32_t)(xin > 0) << i;
-        right_bits |= (uint32_t)(xin < g.wcell - 1) << i;
+        const int xl = 4 * lane + i;
+        ok_bits |= (uint32_t)(xg + i >= ORB_EDGE && xg + i < x_hi && xl >= 3 && xl <= 252) << i;
     }
+    __syncthreads();                                           // map is zero
 
-    auto load_row = [&](int y, uint32_t (&dst)[3]) {
-        if (col_ok) {
-            const Row12 v = *reinterpret_cast<const Row12*>(P + (ptrdiff_t)y * g.pitch);
-            dst[0] = v.a; dst[1] = v.b; dst[2] = v.c;
-        } else {
-            dst[0] = dst[1] = dst[2] = 0;
-        }
-    };
-
-    uint32_t W[7][3];
-    const int r0 = yb - 1;                            // first score row (apron of the band)
-    W[0][0] = W[0][1] = W[0][2] = 0;
+    uint16_t* queue = s_queue[wv];
+    const v2s thr = {(short)(min_th + 1), (short)(min_th + 1)};
+    const v2s zero = {0, 0};
+    const uint8_t* base = plane + (size_t)ORB_OY * g.pitch + (col - 4);
+    const int y_last = g.h + ORB_EDGE - 1;                     // last row of the plane
+#pragma unroll 1
+    for (int grp = 0; grp < 2; grp++) {
+        const int mg = m0 + FT_GROUP * grp;                    // first map row of this step
+        const int rg = y0 - 1 + mg;                            // its level row
+        const int nstep = min(FT_GROUP, nrows - FT_GROUP * grp);
+        uint32_t ctr[FT_GROUP], lft[FT_GROUP], rgt[FT_GROUP], above[3], below[3];
 #pragma unroll
-    for (int j = 0; j < 6; j++) load_row(r0 - 3 + j, W[j + 1]);
-    uint32_t scl[3] = {0, 0, 0}, sc[3] = {0, 0, 0}, scr[3] = {0, 0, 0};   // score rows r-2, r-1, r
-    int nstage = 0;
-    const int r_end = min(yb + F2_RB, y_hi);          // last score row needed (apron below the band)
-    for (int r = r0; r <= r_end; r++) {
-#pragma unroll
-        for (int j = 0; j < 6; j++) { W[j][0] = W[j + 1][0]; W[j][1] = W[j + 1][1]; W[j][2] = W[j + 1][2]; }
-        load_row(r + 3, W[6]);
-        // ---- scores of row r
-        uint32_t snew = 0;
-        if (r >= ORB_EDGE && r < y_hi) {
-            v2s d0[16], d1[16];
-            ring_diffs<0>(W, d0, std::make_index_sequence<16>());
-            ring_diffs<1>(W, d1, std::make_index_sequence<16>());
-            const v2s t0 = fast_pretest(d0), t1 = fast_pretest(d1);
-            const int tmax = max(max((int)t0.x, (int)t0.y), max((int)t1.x, (int)t1.y));
-            if (__ballot(tmax > min_th && ok_bits != 0)) {
-                const v2s S0 = fast_score_packed(d0), S1 = fast_score_packed(d1);
-                const int s0 = S0.x, s1 = S0.y, s2 = S1.x, s3 = S1.y;
-                snew = ((s0 >= min_th && (ok_bits & 1)) ? (uint32_t)s0 : 0u) |
-                       ((s1 >= min_th && (ok_bits & 2)) ? (uint32_t)s1 << 8 : 0u) |
-                       ((s2 >= min_th && (ok_bits & 4)) ? (uint32_t)s2 << 16 : 0u) |
-                       ((s3 >= min_th && (ok_bits & 8)) ? (uint32_t)s3 << 24 : 0u);
+        for (int j = 0; j < FT_GROUP; j++) {
+            const int y = rg + j;
+            if (col_ok && y <= y_last) {
+                const Row12 v = *reinterpret_cast<const Row12*>(base + (ptrdiff_t)y * g.pitch);
+                lft[j] = v.a; ctr[j] = v.b; rgt[j] = v.c;
+            } else {
+                lft[j] = ctr[j] = rgt[j] = 0;
             }
         }
-        scl[0] = scl[1]; scl[1] = scl[2]; sc[0] = sc[1]; sc[1] = sc[2]; scr[0] = scr[1]; scr[1] = scr[2];
-        sc[2] = snew;
-        if (__ballot(snew != 0)) {
-            scl[2] = __shfl_up(snew, 1, 64) >> 24;    // rightmost score of the group to the left
-            scr[2] = __shfl_down(snew, 1, 64) & 0xFF; // leftmost score of the group to the right
-        } else {
-            scl[2] = scr[2] = 0;
-        }
-        // ---- non-maximum suppression of row r-1 inside its cell, emission
-        const int yn = r - 1;
-        if (yn >= yb && yn < y_hi && __ballot(sc[1] != 0)) {
-            const int uy = yn - ORB_EDGE;
-            const int cy = uy / g.hcell, yin = uy - cy * g.hcell;
-            const bool up = yin > 0, dn = yin < g.hcell - 1;
-            // rows as byte strings: [left neighbour, own 4, right neighbour]
-            const unsigned long long x0 = scl[0] | ((unsigned long long)sc[0] << 8) | ((unsigned long long)scr[0] << 40);
-            const unsigned long long x1 = scl[1] | ((unsigned long long)sc[1] << 8) | ((unsigned long long)scr[1] << 40);
-            const unsigned long long x2 = scl[2] | ((unsigned long long)sc[2] << 8) | ((unsigned long long)scr[2] << 40);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int s = (sc[1] >> (8 * i)) & 0xFF;
-                if (!__ballot(s != 0)) continue;
-                const bool l = (left_bits >> i) & 1, rr = (right_bits >> i) & 1;
-                int m = 0;
-                const int a0 = (int)(x0 >> (8 * i)) & 0xFF, a1 = (int)(x0 >> (8 * i + 8)) & 0xFF, a2 = (int)(x0 >> (8 * i + 16)) & 0xFF;
-                const int b0 = (int)(x1 >> (8 * i)) & 0xFF, b2 = (int)(x1 >> (8 * i + 16)) & 0xFF;
-                const int c0 = (int)(x2 >> (8 * i)) & 0xFF, c1 = (int)(x2 >> (8 * i + 8)) & 0xFF, c2 = (int)(x2 >> (8 * i + 16)) & 0xFF;
-                if (up) { m = a1; if (l) m = max(m, a0); if (rr) m = max(m, a2); }
-                if (l) m = max(m, b0);
-                if (rr) m = max(m, b2);
-                if (dn) { m = max(m, c1); if (l) m = max(m, c0); if (rr) m = max(m, c2); }
-                const bool keep = emit && s != 0 && s > m;
-                const unsigned long long km = __ballot(keep);
-                if (!km) continue;
-                if (keep) {
-                    const int slot = nstage + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0));
-                    stage[slot] = make_uint2((uint32_t)(xg + i - ORB_MINB) | ((uint32_t)(yn - ORB_MINB) << 16), (uint32_t)s);
-                    if (s >= ini_th) atomicAdd(&cells[cy * g.ncols + cellx[i]], 1);
+        for (int j = 0; j < 3; j++) {
+            const int ya = rg - 3 + j, yb = rg + FT_GROUP + j;
+            above[j] = col_ok ? *reinterpret_cast<const uint32_t*>(base + (ptrdiff_t)ya * g.pitch + 4) : 0u;
+            below[j] = (col_ok && yb <= y_last) ? *reinterpret_cast<const uint32_t*>(base + (ptrdiff_t)yb * g.pitch + 4) : 0u;
+        }
+        // copy what was loaded into the image tile (tile rows mg .. mg+10 = level rows rg-3 .. rg+7;
+        // other steps and waves write identical bytes to the rows they share)
+        {
+            uint8_t* t = &s_img[mg * FT_P + 4 * lane];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                *reinterpret_cast<uint32_t*>(t + j * FT_P) = above[j];
+                if (mg + 3 + FT_GROUP + j < FT_IMG_ROWS) *reinterpret_cast<uint32_t*>(t + (3 + FT_GROUP + j) * FT_P) = below[j];
+            }
+#pragma unroll
+            for (int j = 0; j < FT_GROUP; j++) *reinterpret_cast<uint32_t*>(t + (3 + j) * FT_P) = ctr[j];
+        }
+        uint32_t bits = 0;
+#pragma unroll
+        for (int j = 0; j < FT_GROUP; j++) {
+            const int r = rg + j;
+            if (j >= nstep || r < ORB_EDGE || r >= y_hi) continue;   // wave-uniform
+            const uint32_t up = j >= 3 ? ctr[j >= 3 ? j - 3 : 0] : above[j < 3 ? j : 0];
+            const uint32_t dn = j + 3 < FT_GROUP ? ctr[j + 3 < FT_GROUP ? j + 3 : 0] : below[j + 3 >= FT_GROUP ? j + 3 - FT_GROUP : 0];
+            // pair 0 = pixels 0,1 (bytes 4,5 of [lft ctr rgt]); pair 1 = pixels 2,3 (bytes 6,7)
+            const v2s c0 = pick2<0>(ctr[j], ctr[j]), c1 = pick2<2>(ctr[j], ctr[j]);
+            const v2s n0 = c0 - pick2<0>(dn, dn), n1 = c1 - pick2<2>(dn, dn);               // ring 0  = (0,+3)
+            const v2s s0 = c0 - pick2<0>(up, up), s1 = c1 - pick2<2>(up, up);               // ring 8  = (0,-3)
+            const v2s e0 = c0 - pick2<3>(rgt[j], ctr[j]), e1 = c1 - pick2<1>(rgt[j], rgt[j]);   // ring 4  = (+3,0)
+            const v2s w0 = c0 - pick2<1>(ctr[j], lft[j]), w1 = c1 - pick2<3>(ctr[j], lft[j]);   // ring 12 = (-3,0)
+            const v2s t0 = pmax(pmin(pmax(n0, s0), pmax(e0, w0)), zero - pmax(pmin(n0, s0), pmin(e0, w0)));
+            const v2s t1 = pmax(pmin(pmax(n1, s1), pmax(e1, w1)), zero - pmax(pmin(n1, s1), pmin(e1, w1)));
+            // pixel passes iff its half of t is >= min_th + 1: sign bit of (t - (min_th+1)) clear
+            const uint32_t q0 = ~v2u(t0 - thr), q1 = ~v2u(t1 - thr);
+            const uint32_t pass = (((q0 >> 15) & 1) | ((q0 >> 30) & 2) | ((q1 >> 13) & 4) | ((q1 >> 28) & 8)) & ok_bits;
+            bits |= pass << (4 * j);
+        }
+        // exact scores of the survivors (their rings lie in tile rows this wave has just written)
+        if (__ballot(bits != 0)) {
+            const uint32_t cnt = __popc(bits);
+            const uint32_t incl = wave_scan_incl(cnt);
+            const int total = (int)__shfl(incl, 63, 64);
+            for (int wb = 0; wb < total; wb += FT_QUEUE) {
+                fast_fill_queue(bits, (int)(incl - cnt), wb, lane, mg, queue);
+                const int nw = min(FT_QUEUE, total - wb);
+                for (int q = 0; q < nw; q += 64) fast_score_queue(queue + q, min(64, nw - q), lane, s_img, min_th, s_map);
+            }
+        }
+    }
+    __syncthreads();                                           // all scores of the tile are in the map
+
+    // ---- non-maximum suppression inside the cell and emission, map rows 1+8*wv .. 8+8*wv
+    const int segi = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 4 + wv;
+    uint2* out = seg + (size_t)f * seg_per_frame + g.seg_off + (size_t)segi * FT_SEGCAP;
+    int nout = 0;
+    const int mh = 1 + 8 * wv;
+    uint32_t bits = 0;
+    if (lane >= 1 && lane <= 62) {                             // lanes 0 and 63 hold neighbour columns only
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (y0 - 1 + mh + j >= y_hi) continue;
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(&s_map[(mh + j) * FT_P + 4 * lane]);
+            const uint32_t nz = ((v & 0xFF) != 0) | (((v & 0xFF00) != 0) << 1) | (((v & 0xFF0000) != 0) << 2) | (((v >> 24) != 0) << 3);
+            bits |= nz << (4 * j);
+        }
+    }
+    if (__ballot(bits != 0)) {
+        const uint32_t cnt = __popc(bits);
+        const uint32_t incl = wave_scan_incl(cnt);
+        const int total = (int)__shfl(incl, 63, 64);
+        for (int wb = 0; wb < total; wb += FT_QUEUE) {
+            fast_fill_queue(bits, (int)(incl - cnt), wb, lane, mh, queue);
+            const int nw = min(FT_QUEUE, total - wb);
+            for (int q = 0; q < nw; q += 64) {
+                bool keep = false;
+                int x = 0, y = 0, s = 0;
+                if (q + lane < nw) {
+                    const int e = queue[q + lane];
+                    const int xl = e & 0xFF, m = e >> 8;
+                    const uint8_t* c = &s_map[m * FT_P + xl];
+                    s = c[0];
+                    x = xs - 4 + xl; y = y0 - 1 + m;
+                    const int ux = x - ORB_EDGE, uy = y - ORB_EDGE;
+                    const int xin = ux - (int)__umulhi((uint32_t)ux, g.wcell_magic) * g.wcell;
+                    const int yin = uy - (int)__umulhi((uint32_t)uy, g.hcell_magic) * g.hcell;
+                    // neighbours in another cell (or outside the detectable area, where the map is 0) do not count
+                    const bool l = xin > 0, r = xin < g.wcell - 1, u = yin > 0, d = yin < g.hcell - 1;
+                    int mx = 0;
+                    if (l) mx = c[-1];
+                    if (r) mx = max(mx, (int)c[1]);
+                    if (u) { mx = max(mx, (int)c[-FT_P]); if (l) mx = max(mx, (int)c[-FT_P - 1]); if (r) mx = max(mx, (int)c[-FT_P + 1]); }
+                    if (d) { mx = max(mx, (int)c[FT_P]); if (l) mx = max(mx, (int)c[FT_P - 1]); if (r) mx = max(mx, (int)c[FT_P + 1]); }
+                    keep = s > mx;
                 }
-                nstage += __popcll(km);
-            }
-            if (nstage > F2_STAGE - 256) {
-                fast_flush(stage, nstage, out, counter, g.cand_cap, status, lane);
-                nstage = 0;
+                const unsigned long long km = __ballot(keep);
+                if (keep) {
+                    const int slot = nout + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0));
+                    if (slot < FT_SEGCAP) out[slot] = make_uint2((uint32_t)(x - ORB_MINB) | ((uint32_t)(y - ORB_MINB) << 16), (uint32_t)s);
+                }
+                nout += __popcll(km);
             }
         }
     }
-    fast_flush(stage, nstage, out, counter, g.cand_cap, status, lane);
+    if (lane == 0) {
+        if (nout > FT_SEGCAP) { atomicOr(status, 1); nout = FT_SEGCAP; }
+        seg_count[(size_t)f * segc_per_frame + g.segc_off + segi] = nout;
+    }
 }

@@ -3,7 +3,7 @@
 // Pipeline per pass over F frames (all frames of a pass share one launch, blockIdx.z/y = frame):
 //   k_level0     input image -> level 0 plane with REFLECT_101 border     (src/ORBextractor.cc:1127-1128)
 //   k_resize     level l-1 -> level l, cv::resize 8U INTER_LINEAR + border (src/ORBextractor.cc:1120-1123)
-//   k_fast       FAST-9 score, per-cell NMS, per-cell iniTh count, append  (orb_fast.h; src/ORBextractor.cc:789-829)
+//   k_fast       FAST-9 score, per-cell NMS, survivors into per-wave segments (orb_fast.h; src/ORBextractor.cc:789-829)
 //   k_quadtree   DistributeOctTree, one workgroup per (level, frame)       (src/ORBextractor.cc:539-763)
 //   k_describe   IC_Angle + 7x7 blur of the 45x45 patch + rBRIEF, one wave per keypoint
 //                                                                          (src/ORBextractor.cc:77-147,1085-1101)
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, Level
 //               build the new list = children in reverse creation order, then the unsplit nodes
 //   key step  : relabel every key to its new node and count the keys per child quadrant
 // Node counts and the "best response per node" reduction are order-independent, so the result
-// does not depend on the order in which k_fast appended the candidates. Ties between equal
+// does not depend on the order in which the candidates were gathered. Ties between equal
 // responses go to the key that comes first in the reference's candidate order (cell row, cell
 // column, raster), encoded as `ord`. Equal-size nodes in the final expansion rounds are taken in
 // reverse creation order (the reference compares heap addresses there).
@@ -132,14 +132,17 @@ __device__ __forceinline__ int qt_quadrant(uint32_t bx, uint32_t by, int x, int 
 }
 
 __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restrict__ plan,
-                                                         uint2* __restrict__ cand,
-                                                         const int* __restrict__ cand_count,
-                                                         const int* __restrict__ cell_ini,
+                                                         const uint2* __restrict__ seg,
+                                                         const int* __restrict__ seg_count,
+                                                         uint2* __restrict__ keys_all,
+                                                         int* __restrict__ key_count,
                                                          LevelKp* __restrict__ lvl_kp,
-                                                         int* __restrict__ lvl_cnt) {
+                                                         int* __restrict__ lvl_cnt,
+                                                         int* __restrict__ status) {
     extern __shared__ __align__(16) uint32_t smem[];
     __shared__ uint32_t s_tmp[8];
     __shared__ uint32_t s_red[4];
+    __shared__ int s_nkeys;
     const int tid = threadIdx.x;
     const int level = blockIdx.x, f = blockIdx.y;
     const LevelGeom g = plan->lv[level];
@@ -157,10 +160,44 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         q.ordarr = p; p += M;
         q.cbase = p; p += M;
     }
-    uint2* keys = cand + (size_t)f * plan->cand_per_frame + g.cand_off;
-    const int nkeys = min(cand_count[f * plan->nlevels + level], g.cand_cap);
-    const int* cells = cell_ini + (size_t)f * plan->cells_per_frame + g.cell_off;
+    uint32_t* cellbits = smem + 20 * M;            // one bit per FAST cell: it has a survivor >= iniTh
+    uint2* keys = keys_all + (size_t)f * plan->keys_per_frame + g.keys_off;
     const int ini_th = plan->ini_th;
+
+    // ---- gather the FAST survivors of this level from the (tile, wave) segments into `keys`
+    // (any order: everything below is order-independent) and mark the cells that have a survivor
+    // at the initial threshold (src/ORBextractor.cc:808-816: a cell is re-run at minThFAST only when
+    // it found nothing at iniThFAST)
+    const int ncells = g.ncols * g.nrows;
+    for (int i = tid; i < (ncells + 31) / 32; i += QT_THREADS) cellbits[i] = 0;
+    if (tid == 0) s_nkeys = 0;
+    __syncthreads();
+    {
+        const int nseg = g.ntx * g.nty * 4;
+        const int* sc = seg_count + (size_t)f * plan->segc_per_frame + g.segc_off;
+        const uint2* sbase = seg + (size_t)f * plan->seg_per_frame + g.seg_off;
+        for (int sidx = tid; sidx < nseg; sidx += QT_THREADS) {
+            const int n = sc[sidx];
+            if (n <= 0) continue;
+            const int base = atomicAdd(&s_nkeys, n);
+            const uint2* src = sbase + (size_t)sidx * FT_SEGCAP;
+            for (int i = 0; i < n; i++) {
+                const uint2 e = src[i];
+                if (base + i < g.keys_cap) keys[base + i] = e;
+                if ((int)(e.y & 0xFF) >= ini_th) {
+                    const int x = e.x & 0xFFFF, y = e.x >> 16;
+                    const int c = ((y - 3) / g.hcell) * g.ncols + (x - 3) / g.wcell;
+                    atomicOr(&cellbits[c >> 5], 1u << (c & 31));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (s_nkeys > g.keys_cap) atomicOr(status, 1);
+        key_count[f * plan->nlevels + level] = min(s_nkeys, g.keys_cap);
+    }
+    const int nkeys = min(s_nkeys, g.keys_cap);
 
     // ---- roots (src/ORBextractor.cc:543-585)
     int L = g.n_ini;            // length of the node array (round 0 may contain empty roots)
@@ -179,7 +216,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         const int cx = (x - 3) / g.wcell, cy = (y - 3) / g.hcell;
         uint32_t lab = ORB_DEAD_LABEL;
         uint32_t qd = 0;
-        if (s >= ini_th || cells[cy * g.ncols + cx] == 0) {
+        const int cell = cy * g.ncols + cx;
+        if (s >= ini_th || ((cellbits[cell >> 5] >> (cell & 31)) & 1) == 0) {
             int root = (int)__fdiv_rn((float)x, g.hx);
             root = min(max(root, 0), L - 1);
             qd = qt_quadrant(q.box[0][2 * root], q.box[0][2 * root + 1], x, y);

@@ -47,9 +47,10 @@ struct orbhip_extractor {
     PlanDev* d_plan = nullptr;
     RsTab* d_tabs = nullptr;
     uint8_t* d_pyr = nullptr;
-    uint2* d_cand = nullptr;
-    int* d_cand_count = nullptr;   // [frames][nlevels]
-    int* d_cell_ini = nullptr;     // [frames][cells_per_frame]
+    uint2* d_seg = nullptr;        // [frames][seg_per_frame]   FAST output segments
+    int* d_seg_count = nullptr;    // [frames][segc_per_frame]
+    uint2* d_keys = nullptr;       // [frames][keys_per_frame]  compact keys of the quadtree
+    int* d_key_count = nullptr;    // [frames][nlevels]
     LevelKp* d_lvl_kp = nullptr;   // [frames][kp_per_frame]
     int* d_lvl_cnt = nullptr;      // [frames][nlevels]
     int* d_status = nullptr;       // bit0 candidate overflow, bit1 output capacity
@@ -84,8 +85,8 @@ void dfree(T*& p) {
 }
 
 void free_plan(orbhip_extractor* e) {
-    dfree(e->d_plan); dfree(e->d_tabs); dfree(e->d_pyr); dfree(e->d_cand); dfree(e->d_cand_count);
-    dfree(e->d_cell_ini); dfree(e->d_lvl_kp); dfree(e->d_lvl_cnt);
+    dfree(e->d_plan); dfree(e->d_tabs); dfree(e->d_pyr); dfree(e->d_seg); dfree(e->d_seg_count);
+    dfree(e->d_keys); dfree(e->d_key_count); dfree(e->d_lvl_kp); dfree(e->d_lvl_cnt);
     e->plan_w = e->plan_h = e->plan_frames = 0;
 }
 
@@ -138,9 +139,9 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames) {
     blur_taps(e->prm.blur_variant, P.blur_taps);
     P.blur_ties_even = e->prm.blur_variant == ORBHIP_BLUR_LEGACY;
     std::memcpy(P.umax, e->umax, sizeof(P.umax));
-    size_t pyr_off = 0, cand_off = 0;
-    int cell_off = 0, kp_off = 0, tab_off = 0;
-    int max_nodes = 0;
+    size_t pyr_off = 0, keys_off = 0, seg_off = 0;
+    int segc_off = 0, kp_off = 0, tab_off = 0;
+    size_t max_qt_words = 0;
     for (int l = 0; l < nl; l++) {
         LevelGeom& g = P.lv[l];
         g.w = cv_round((float)w * e->inv_sf[l]);          // src/ORBextractor.cc:1111-1112
@@ -159,33 +160,41 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames) {
         if (g.ncols < 1 || g.nrows < 1) {
             // the reference visits no cell on such a level: it contributes no keypoints
             g.ncols = g.nrows = 0; g.wcell = g.hcell = 1;
-            g.n_ini = 0; g.hx = 1.f; g.node_cap = 1; g.cand_cap = 1;
+            g.n_ini = 0; g.hx = 1.f; g.node_cap = 1; g.keys_cap = 1;
+            g.ntx = g.nty = 0;
         } else {
             g.wcell = (int)std::ceil(width / g.ncols);
             g.hcell = (int)std::ceil(height / g.nrows);
+            g.wcell_magic = (unsigned)((1ull << 32) / (unsigned)g.wcell + 1);
+            g.hcell_magic = (unsigned)((1ull << 32) / (unsigned)g.hcell + 1);
             g.n_ini = (int)std::round(width / (float)(g.maxby - ORB_MINB));   // src/ORBextractor.cc:543
             if (g.n_ini < 1) { e->err = "image too narrow for the quadtree (nIni == 0)"; return ORBHIP_ERR_GEOMETRY; }
             g.hx = width / (float)g.n_ini;                                  // src/ORBextractor.cc:545
             // strict local maxima inside a cell: at most one per 2x2 block
             const int dw = g.w - 2 * ORB_EDGE, dh = g.h - 2 * ORB_EDGE;
-            g.cand_cap = ((dw + 1) / 2 + g.ncols) * ((dh + 1) / 2 + g.nrows);
+            g.keys_cap = ((dw + 1) / 2 + g.ncols) * ((dh + 1) / 2 + g.nrows);
             g.node_cap = std::max(e->per_level[l] + 3, 4 * g.n_ini) + 1;
+            g.ntx = (g.w - ORB_EDGE - ORB_MINB + FT_COLS - 1) / FT_COLS;
+            g.nty = (dh + FT_ROWS - 1) / FT_ROWS;
         }
-        g.cell_off = cell_off; cell_off += g.ncols * g.nrows;
-        g.cand_off = cand_off; cand_off += g.cand_cap;
+        g.seg_off = seg_off; seg_off += (size_t)g.ntx * g.nty * 4 * FT_SEGCAP;
+        g.segc_off = segc_off; segc_off += g.ntx * g.nty * 4;
+        g.keys_off = keys_off; keys_off += g.keys_cap;
+        max_qt_words = std::max(max_qt_words, (size_t)20 * g.node_cap + (size_t)(g.ncols * g.nrows + 31) / 32);
         g.quota = e->per_level[l];
         g.kp_off = kp_off; kp_off += g.node_cap;
         g.scale = e->sf[l];
         g.patch_size = (float)(int)(31 * e->sf[l]);        // src/ORBextractor.cc:837
         g.xtab_off = tab_off; tab_off += g.w;
         g.ytab_off = tab_off; tab_off += g.h;
-        max_nodes = std::max(max_nodes, g.node_cap);
     }
-    P.cells_per_frame = std::max(cell_off, 1);
-    P.cand_per_frame = cand_off;
+    P.seg_per_frame = std::max(seg_off, (size_t)1);
+    P.segc_per_frame = std::max(segc_off, 1);
+    P.keys_per_frame = keys_off;
     P.kp_per_frame = kp_off;
     e->pyr_bytes_per_frame = pyr_off / frames;
-    e->qt_lds = (size_t)max_nodes * 4 * (2 + 4 + 2 + 8 + 1 + 1 + 1 + 1);
+    // node arrays of k_quadtree (20 words per node) plus its per-cell bit mask
+    e->qt_lds = max_qt_words * 4;
     if (e->qt_lds > 160 * 1024 - 256) { e->err = "nfeatures per level too large for the on-chip quadtree"; return ORBHIP_ERR_ARG; }
     std::vector<RsTab> tabs((size_t)std::max(tab_off, 1));
     for (int l = 1; l < nl; l++)
@@ -194,9 +203,10 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames) {
     HIP_TRY(e, hipMalloc(&e->d_plan, sizeof(PlanDev)));
     HIP_TRY(e, hipMalloc(&e->d_tabs, tabs.size() * sizeof(RsTab)));
     HIP_TRY(e, hipMalloc(&e->d_pyr, pyr_off + 64));
-    HIP_TRY(e, hipMalloc(&e->d_cand, (size_t)P.cand_per_frame * frames * sizeof(uint2)));
-    HIP_TRY(e, hipMalloc(&e->d_cand_count, (size_t)frames * nl * sizeof(int)));
-    HIP_TRY(e, hipMalloc(&e->d_cell_ini, (size_t)frames * P.cells_per_frame * sizeof(int)));
+    HIP_TRY(e, hipMalloc(&e->d_seg, (size_t)P.seg_per_frame * frames * sizeof(uint2)));
+    HIP_TRY(e, hipMalloc(&e->d_seg_count, (size_t)P.segc_per_frame * frames * sizeof(int)));
+    HIP_TRY(e, hipMalloc(&e->d_keys, (size_t)P.keys_per_frame * frames * sizeof(uint2)));
+    HIP_TRY(e, hipMalloc(&e->d_key_count, (size_t)frames * nl * sizeof(int)));
     HIP_TRY(e, hipMalloc(&e->d_lvl_kp, (size_t)frames * P.kp_per_frame * sizeof(LevelKp)));
     HIP_TRY(e, hipMalloc(&e->d_lvl_cnt, (size_t)frames * nl * sizeof(int)));
     HIP_TRY(e, hipMemcpyAsync(e->d_plan, &P, sizeof(PlanDev), hipMemcpyHostToDevice, e->stream));
@@ -231,8 +241,6 @@ int run_pass(orbhip_extractor* e, hipStream_t s, const uint8_t* d_imgs, int fram
              size_t frame_stride, float* d_kp, uint8_t* d_desc, int* d_counts, int cap, int frame0) {
     const PlanDev& P = e->plan;
     const int nl = P.nlevels;
-    HIP_TRY(e, hipMemsetAsync(e->d_cand_count, 0, (size_t)frames * nl * sizeof(int), s));
-    HIP_TRY(e, hipMemsetAsync(e->d_cell_ini, 0, (size_t)frames * P.cells_per_frame * sizeof(int), s));
     const dim3 blk2(64, 4);
     {
         SpanGuard t(e, s, KC_LEVEL0);
@@ -251,18 +259,16 @@ int run_pass(orbhip_extractor* e, hipStream_t s, const uint8_t* d_imgs, int fram
     for (int l = 0; l < nl; l++) {
         const LevelGeom& g = P.lv[l];
         if (g.ncols < 1) continue;
-        const int dw = g.w - 2 * ORB_EDGE, dh = g.h - 2 * ORB_EDGE;
-        if (dw < 1 || dh < 1) continue;
         SpanGuard t(e, s, KC_FAST);
-        const int nstrips = (g.w - ORB_EDGE - ORB_MINB + F2_COLS - 1) / F2_COLS, nbands = (dh + F2_RB - 1) / F2_RB;
-        hipLaunchKernelGGL(k_fast, dim3(nstrips, (nbands + 3) / 4, frames), dim3(256), 0, s,
-                           e->d_pyr, g, l, nl, P.ini_th, P.min_th, P.cells_per_frame, P.cand_per_frame, nbands,
-                           e->d_cand, e->d_cand_count, e->d_cell_ini, e->d_status);
+        hipLaunchKernelGGL(k_fast, dim3(g.ntx, g.nty, frames), dim3(256), 0, s,
+                           e->d_pyr, g, P.min_th, P.seg_per_frame, P.segc_per_frame,
+                           e->d_seg, e->d_seg_count, e->d_status);
     }
     {
         SpanGuard t(e, s, KC_QUADTREE);
         hipLaunchKernelGGL(k_quadtree, dim3(nl, frames), dim3(QT_THREADS), e->qt_lds, s,
-                           e->d_plan, e->d_cand, e->d_cand_count, e->d_cell_ini, e->d_lvl_kp, e->d_lvl_cnt);
+                           e->d_plan, e->d_seg, e->d_seg_count, e->d_keys, e->d_key_count, e->d_lvl_kp, e->d_lvl_cnt,
+                           e->d_status);
     }
     {
         SpanGuard t(e, s, KC_DESCRIBE);
@@ -516,18 +522,17 @@ int orbhip_debug_candidates(orbhip_extractor* e, int frame, int level, orbhip_ca
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipDeviceSynchronize());
     int n = 0;
-    HIP_TRY(e, hipMemcpy(&n, e->d_cand_count + frame * P.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
-    n = std::min(n, g.cand_cap);
+    HIP_TRY(e, hipMemcpy(&n, e->d_key_count + frame * P.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    n = std::min(n, g.keys_cap);
     std::vector<uint2> raw((size_t)std::max(n, 1));
-    std::vector<int> cells((size_t)g.ncols * g.nrows);
-    HIP_TRY(e, hipMemcpy(raw.data(), e->d_cand + (size_t)frame * P.cand_per_frame + g.cand_off, (size_t)n * sizeof(uint2), hipMemcpyDeviceToHost));
-    HIP_TRY(e, hipMemcpy(cells.data(), e->d_cell_ini + (size_t)frame * P.cells_per_frame + g.cell_off, cells.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(raw.data(), e->d_keys + (size_t)frame * P.keys_per_frame + g.keys_off, (size_t)n * sizeof(uint2), hipMemcpyDeviceToHost));
     struct Item { unsigned ord; orbhip_candidate c; };
     std::vector<Item> items;
     for (int i = 0; i < n; i++) {
+        // keys the quadtree dropped by the per-cell threshold rule (src/ORBextractor.cc:808-816) carry the dead label
+        if ((raw[i].y >> 10) == ORB_DEAD_LABEL) continue;
         const int x = raw[i].x & 0xFFFF, y = raw[i].x >> 16, s = raw[i].y & 0xFF;
         const int cx = (x - 3) / g.wcell, cy = (y - 3) / g.hcell;
-        if (s < P.ini_th && cells[cy * g.ncols + cx] != 0) continue;   // src/ORBextractor.cc:808-816
         const unsigned ord = (unsigned)(((cy * g.ncols + cx) * g.hcell + (y - 3 - cy * g.hcell)) * g.wcell + (x - 3 - cx * g.wcell));
         items.push_back(Item{ord, orbhip_candidate{x, y, s}});
     }

@@ -6,12 +6,13 @@ constructor arguments, `__call__(image, mask)` for operator(), the six accessors
 import fails loudly when the library is missing.
 """
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libORBhip.so"
+LIB_PATH = Path(os.environ.get("ORBHIP_LIB", _PKG / "libORBhip.so"))   # override only for kernel experiments
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
