@@ -20,50 +20,108 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Level 0: copy of the input with the 19-px REFLECT_101 border. One thread writes one dword.
+// Level 0: copy of the input with the 19-px REFLECT_101 border. One thread writes 16 bytes of one
+// row; groups that lie inside the image and are 16-byte aligned in the source move as one dwordx4.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src, size_t row_stride,
                                                 size_t frame_stride, uint8_t* __restrict__ pyr,
-                                                LevelGeom g, int ndw) {
-    const int c4 = blockIdx.x * 64 + threadIdx.x;
+                                                LevelGeom g, int n16, int src_aligned16) {
+    const int c16 = blockIdx.x * 64 + threadIdx.x;
     const int r = blockIdx.y * 4 + threadIdx.y;
     const int f = blockIdx.z;
-    if (c4 >= ndw || r >= g.rows) return;
+    if (c16 >= n16 || r >= g.rows) return;
     const uint8_t* S = src + (size_t)f * frame_stride + (size_t)reflect101(r - ORB_OY, g.h) * row_stride;
-    uint32_t out = 0;
+    const int x0 = c16 * 16 - ORB_OX;
+    uint4 out;
+    if (src_aligned16 && x0 >= 0 && x0 + 16 <= g.w) {
+        out = *reinterpret_cast<const uint4*>(S + x0);
+    } else {
+        uint32_t o[4];
 #pragma unroll
-    for (int b = 0; b < 4; b++) out |= (uint32_t)S[reflect101(c4 * 4 + b - ORB_OX, g.w)] << (8 * b);
+        for (int d = 0; d < 4; d++) {
+            o[d] = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) o[d] |= (uint32_t)S[reflect101(x0 + 4 * d + b, g.w)] << (8 * b);
+        }
+        out = make_uint4(o[0], o[1], o[2], o[3]);
+    }
     uint8_t* D = pyr + g.pyr_off + (size_t)f * g.plane_bytes + (size_t)r * g.pitch;
-    reinterpret_cast<uint32_t*>(D)[c4] = out;
+    reinterpret_cast<uint4*>(D)[c16] = out;
 }
 
 // ------------------------------------------------------------------------------------------------
 // Level l from level l-1: cv::resize(8UC1, INTER_LINEAR) fixed-point arithmetic, border included
 // (a border pixel is the resized value at the reflected coordinate, which is what copyMakeBorder
-// copies there). Tap tables are built on the host exactly as OpenCV builds xofs/ialpha/yofs/ibeta.
+// copies there). The tap tables are built on the host exactly as OpenCV builds xofs/ialpha and
+// yofs/ibeta, and are indexed by DEVICE column / row, so the reflection is already folded in.
+//
+// A lane produces 4 adjacent pixels of RS_RPT consecutive rows. The source bytes of the 4 pixels
+// lie inside 12 bytes starting at a 4-aligned offset (checked on the host), so one dwordx3 load
+// per source row feeds them; v_perm_b32 pulls the two taps of a pixel into 16-bit halves and
+// v_dot2_i32_i16 applies the two 11-bit weights. Consecutive output rows usually share a source
+// row; its horizontal pass is reused.
 // ------------------------------------------------------------------------------------------------
+#define RS_RPT 4
+
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, LevelGeom gs, LevelGeom gd,
                                                 const RsTab* __restrict__ tabs, int ndw) {
     const int c4 = blockIdx.x * 64 + threadIdx.x;
-    const int r = blockIdx.y * 4 + threadIdx.y;
+    const int r0 = (blockIdx.y * 4 + threadIdx.y) * RS_RPT;
     const int f = blockIdx.z;
-    if (c4 >= ndw || r >= gd.rows) return;
-    const RsTab ty = tabs[gd.ytab_off + reflect101(r - ORB_OY, gd.h)];
-    const uint8_t* S = pyr + gs.pyr_off + (size_t)f * gs.plane_bytes + ORB_OX;
-    const uint8_t* S0 = S + (size_t)(ty.s0 + ORB_OY) * gs.pitch;
-    const uint8_t* S1 = S + (size_t)(ty.s1 + ORB_OY) * gs.pitch;
-    const int b0 = ty.a0, b1 = ty.a1;
-    uint32_t out = 0;
+    if (c4 >= ndw || r0 >= gd.rows) return;
+    // x side: the same for every row
+    const uint4* tx = reinterpret_cast<const uint4*>(tabs + gd.xtab_off + c4 * 4);
+    const uint4 ta = tx[0], tb = tx[1];
+    const uint32_t pos[4] = {ta.x, ta.z, tb.x, tb.z};          // s0 | s1 << 16
+    const uint32_t wgt[4] = {ta.y, ta.w, tb.y, tb.w};          // a0 | a1 << 16
+    const int s00 = pos[0] & 0xFFFF, s01 = pos[1] & 0xFFFF, s02 = pos[2] & 0xFFFF, s03 = pos[3] & 0xFFFF;
+    const int base = min(min(s00, s01), min(s02, s03)) & ~3;
+    uint32_t sel[4];
+    bool hi[4];
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-        const RsTab tx = tabs[gd.xtab_off + reflect101(c4 * 4 + b - ORB_OX, gd.w)];
-        const int h0 = S0[tx.s0] * tx.a0 + S0[tx.s1] * tx.a1;
-        const int h1 = S1[tx.s0] * tx.a0 + S1[tx.s1] * tx.a1;
-        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-        out |= (uint32_t)(v > 255 ? 255 : v) << (8 * b);
+    for (int i = 0; i < 4; i++) {
+        const int o = (int)(pos[i] & 0xFFFF) - base;           // 0 .. 10
+        hi[i] = o >= 4;
+        const uint32_t idx = (uint32_t)(hi[i] ? o - 4 : o);     // byte index inside the chosen dword pair
+        sel[i] = idx | (0x0Cu << 8) | ((idx + 1) << 16) | (0x0Cu << 24);
     }
-    uint8_t* D = pyr + gd.pyr_off + (size_t)f * gd.plane_bytes + (size_t)r * gd.pitch;
-    reinterpret_cast<uint32_t*>(D)[c4] = out;
+    const uint8_t* S = pyr + gs.pyr_off + (size_t)f * gs.plane_bytes + (size_t)ORB_OY * gs.pitch + ORB_OX + base;
+    uint8_t* D = pyr + gd.pyr_off + (size_t)f * gd.plane_bytes;
+    const RsTab* ytab = tabs + gd.ytab_off;
+    int prev_row = -1;
+    int hprev[4] = {0, 0, 0, 0};
+    auto hpass = [&](int srow, int (&h)[4]) {
+        const Row12 v = *reinterpret_cast<const Row12*>(S + (size_t)srow * gs.pitch);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t p = __builtin_amdgcn_perm(hi[i] ? v.c : v.b, hi[i] ? v.b : v.a, sel[i]);   // tap0 | tap1 << 16
+            h[i] = __builtin_amdgcn_sdot2(u2v(p), u2v(wgt[i]), 0, false) >> 4;
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < RS_RPT; k++) {
+        const int r = r0 + k;
+        if (r >= gd.rows) break;
+        const RsTab ty = ytab[r];
+        int h0[4], h1[4];
+        if ((int)ty.s0 == prev_row) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) h0[i] = hprev[i];
+        } else {
+            hpass(ty.s0, h0);
+        }
+        hpass(ty.s1, h1);
+        prev_row = ty.s1;
+        const int b0 = ty.a0, b1 = ty.a1;
+        uint32_t out = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            hprev[i] = h1[i];
+            const int v = (((b0 * h0[i]) >> 16) + ((b1 * h1[i]) >> 16) + 2) >> 2;     // <= 255 by construction
+            out |= (uint32_t)v << (8 * i);
+        }
+        reinterpret_cast<uint32_t*>(D + (size_t)r * gd.pitch)[c4] = out;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

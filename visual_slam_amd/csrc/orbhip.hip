@@ -116,6 +116,12 @@ void build_resize_tabs(int sw, int sh, int dw, int dh, RsTab* xt, RsTab* yt) {
     }
 }
 
+int reflect101_host(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
 void blur_taps(int variant, int taps[4]) {   // cv::getGaussianKernel(7, 2, CV_32F) scaled by 256
     double k[7], sum = 0;
     for (int i = 0; i < 7; i++) { double x = i - 3; float t = (float)std::exp(-0.5 / 4.0 * x * x); k[i] = t; sum += t; }
@@ -185,8 +191,9 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames) {
         g.kp_off = kp_off; kp_off += g.node_cap;
         g.scale = e->sf[l];
         g.patch_size = (float)(int)(31 * e->sf[l]);        // src/ORBextractor.cc:837
-        g.xtab_off = tab_off; tab_off += g.w;
-        g.ytab_off = tab_off; tab_off += g.h;
+        // resize tap tables are indexed by device column / row (border reflection folded in)
+        g.xtab_off = tab_off; tab_off += (ORB_OX + g.w + ORB_EDGE + 3) / 4 * 4;
+        g.ytab_off = tab_off; tab_off += (g.rows + 1) & ~1;
     }
     P.seg_per_frame = std::max(seg_off, (size_t)1);
     P.segc_per_frame = std::max(segc_off, 1);
@@ -197,8 +204,20 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames) {
     e->qt_lds = max_qt_words * 4;
     if (e->qt_lds > 160 * 1024 - 256) { e->err = "nfeatures per level too large for the on-chip quadtree"; return ORBHIP_ERR_ARG; }
     std::vector<RsTab> tabs((size_t)std::max(tab_off, 1));
-    for (int l = 1; l < nl; l++)
-        build_resize_tabs(P.lv[l - 1].w, P.lv[l - 1].h, P.lv[l].w, P.lv[l].h, &tabs[P.lv[l].xtab_off], &tabs[P.lv[l].ytab_off]);
+    for (int l = 1; l < nl; l++) {
+        const LevelGeom& g = P.lv[l];
+        std::vector<RsTab> xt((size_t)g.w), yt((size_t)g.h);
+        build_resize_tabs(P.lv[l - 1].w, P.lv[l - 1].h, g.w, g.h, xt.data(), yt.data());
+        const int ncol = (ORB_OX + g.w + ORB_EDGE + 3) / 4 * 4;
+        for (int c = 0; c < ncol; c++) tabs[g.xtab_off + c] = xt[reflect101_host(c - ORB_OX, g.w)];
+        for (int r = 0; r < g.rows; r++) tabs[g.ytab_off + r] = yt[reflect101_host(r - ORB_OY, g.h)];
+        // k_resize feeds the 4 pixels of a lane from one 12-byte load at a 4-aligned source offset
+        for (int c = 0; c < ncol; c += 4) {
+            int lo = 1 << 30, hi = 0;
+            for (int i = 0; i < 4; i++) { lo = std::min(lo, (int)tabs[g.xtab_off + c + i].s0); hi = std::max(hi, (int)tabs[g.xtab_off + c + i].s0); }
+            if (hi + 1 - (lo & ~3) > 11) { e->err = "scale factor too large for the resize kernel (must be <= 2)"; return ORBHIP_ERR_ARG; }
+        }
+    }
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipMalloc(&e->d_plan, sizeof(PlanDev)));
     HIP_TRY(e, hipMalloc(&e->d_tabs, tabs.size() * sizeof(RsTab)));
@@ -245,15 +264,16 @@ int run_pass(orbhip_extractor* e, hipStream_t s, const uint8_t* d_imgs, int fram
     {
         SpanGuard t(e, s, KC_LEVEL0);
         const LevelGeom& g = P.lv[0];
-        const int ndw = (ORB_OX + g.w + ORB_EDGE + 3) / 4;
-        hipLaunchKernelGGL(k_level0, dim3((ndw + 63) / 64, (g.rows + 3) / 4, frames), blk2, 0, s,
-                           d_imgs, row_stride, frame_stride, e->d_pyr, g, ndw);
+        const int n16 = (ORB_OX + g.w + ORB_EDGE + 15) / 16;
+        const int aligned16 = ((uintptr_t)d_imgs % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0);
+        hipLaunchKernelGGL(k_level0, dim3((n16 + 63) / 64, (g.rows + 3) / 4, frames), blk2, 0, s,
+                           d_imgs, row_stride, frame_stride, e->d_pyr, g, n16, aligned16);
     }
     for (int l = 1; l < nl; l++) {
         SpanGuard t(e, s, KC_RESIZE);
         const LevelGeom& g = P.lv[l];
         const int ndw = (ORB_OX + g.w + ORB_EDGE + 3) / 4;
-        hipLaunchKernelGGL(k_resize, dim3((ndw + 63) / 64, (g.rows + 3) / 4, frames), blk2, 0, s,
+        hipLaunchKernelGGL(k_resize, dim3((ndw + 63) / 64, (g.rows + 4 * RS_RPT - 1) / (4 * RS_RPT), frames), blk2, 0, s,
                            e->d_pyr, P.lv[l - 1], g, e->d_tabs, ndw);
     }
     for (int l = 0; l < nl; l++) {
