@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
                                                   uint8_t* __restrict__ out_desc, int* __restrict__ out_count,
                                                   int cap, int frame0, int* __restrict__ status) {
     __shared__ __align__(16) uint8_t s_raw[4][DS_RAW_BYTES];
-    __shared__ uint16_t s_hp[4][DS_HP_ENTRIES];
+    __shared__ __align__(16) uint16_t s_hp[4][DS_HP_ENTRIES];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int f = blockIdx.y;
     const int idx = blockIdx.x * 4 + wv;
@@ -529,13 +529,12 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
         out_count[frame0 + f] = min(total, cap);
         if (total > cap) atomicOr(status, 2);
     }
-    // every wave stays until the end (workgroup barriers below); invalid waves work on keypoint 0
-    // of level 0 geometry with all stores suppressed
-    const bool valid = level >= 0 && idx < cap;
-    if (!valid) { level = 0; j = 0; }
+    // Waves are independent from here on (each has its own LDS slices and there is no workgroup
+    // barrier): LDS operations of one wave complete in issue order, so the stage -> read hand-offs
+    // below need no barrier.
+    if (level < 0 || idx >= cap) return;
     const LevelGeom g = plan->lv[level];
-    LevelKp kp = lvl_kp[(size_t)f * plan->kp_per_frame + g.kp_off + j];
-    if (!valid) { kp.x = 22; kp.y = 22; kp.score = 0; }   // any in-bounds position
+    const LevelKp kp = lvl_kp[(size_t)f * plan->kp_per_frame + g.kp_off + j];
     const int kx = kp.x, ky = kp.y;
     const uint8_t* P = pyr + g.pyr_off + (size_t)f * g.plane_bytes;
     // ---- stage rows ky-22..ky+22, 13 aligned dwords per row starting at or before column kx-22
@@ -547,24 +546,23 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
         const uint32_t v = *reinterpret_cast<const uint32_t*>(P + (size_t)(ky - 22 + r + ORB_OY) * g.pitch + colA + c * 4);
         *reinterpret_cast<uint32_t*>(&raw[r * DS_RAW_P + c * 4]) = v;
     }
-    __syncthreads();
-    // ---- IC_Angle (src/ORBextractor.cc:77-104): integer moments over the 749-px disc
+    // ---- IC_Angle (src/ORBextractor.cc:77-104): integer moments over the 749-px disc. Lane = one
+    // column u of one half of the disc; the disc is symmetric, so column u spans |v| <= umax[|u|].
     int m10 = 0, m01 = 0;
     {
-        const int u = (lane & 31) - 15;           // column offset; lane 31/63 idle
+        const int u = (lane & 31) - 15;           // column offset; lanes 31 and 63 idle
         const int half = lane >> 5;               // 0: rows -15..0, 1: rows 1..15
         if (u <= 15) {
-            const int au = u < 0 ? -u : u;
-            for (int t = 0; t < 16; t++) {
-                const int v = half ? t + 1 : -t;
-                if (half && t == 15) break;
-                const int av = v < 0 ? -v : v;
-                if (au <= plan->umax[av]) {
-                    const int I = raw[(22 + v) * DS_RAW_P + off + 22 + u];
-                    m10 += u * I;
-                    m01 += v * I;
-                }
+            const int lim = plan->umax[u < 0 ? -u : u];
+            const uint8_t* c0 = &raw[22 * DS_RAW_P + off + 22 + u];
+            int colsum = 0, vsum = 0;
+            if (half) {
+                for (int v = 1; v <= lim; v++) { const int I = c0[v * DS_RAW_P]; colsum += I; vsum += v * I; }
+            } else {
+                for (int v = 0; v <= lim; v++) { const int I = c0[-v * DS_RAW_P]; colsum += I; vsum -= v * I; }
             }
+            m10 = u * colsum;
+            m01 = vsum;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -573,16 +571,28 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
         }
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
-    // ---- horizontal blur pass: hp[r][c] for rows ky-22..ky+22, columns kx-19..kx+19
+    // ---- horizontal blur pass: hp[r][c] for rows ky-22..ky+22, columns kx-19..kx+19. A lane
+    // produces 4 adjacent sums from 16 staged bytes with byte-aligned dword extracts and
+    // v_dot4_u32_u8 against the taps packed as bytes.
     const int t0 = plan->blur_taps[0], t1 = plan->blur_taps[1], t2 = plan->blur_taps[2], t3 = plan->blur_taps[3];
+    const uint32_t tap_lo = (uint32_t)t3 | ((uint32_t)t2 << 8) | ((uint32_t)t1 << 16) | ((uint32_t)t0 << 24);
+    const uint32_t tap_hi = (uint32_t)t1 | ((uint32_t)t2 << 8) | ((uint32_t)t3 << 16);
     uint16_t* hp = s_hp[wv];
-    for (int i = lane; i < 45 * 39; i += 64) {
-        const int r = i / 39, c = i - r * 39;
-        const uint8_t* s = &raw[r * DS_RAW_P + off + c];   // taps at c .. c+6, centre c+3
-        const int acc = t0 * s[3] + t1 * (s[2] + s[4]) + t2 * (s[1] + s[5]) + t3 * (s[0] + s[6]);
-        hp[r * DS_HP_P + c] = (uint16_t)acc;
+    for (int t = lane; t < 45 * 10; t += 64) {
+        const int r = t / 10, c = (t - r * 10) * 4;            // sums c..c+3 (column 39 is padding)
+        const uint32_t* rw = reinterpret_cast<const uint32_t*>(&raw[r * DS_RAW_P + c]);
+        const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2], d3 = rw[3];
+        const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, off), e1 = __builtin_amdgcn_alignbyte(d2, d1, off),
+                       e2 = __builtin_amdgcn_alignbyte(d3, d2, off);          // bytes off+c .. off+c+11
+        uint32_t acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t lo = k ? __builtin_amdgcn_alignbyte(e1, e0, k) : e0;   // taps at c+k .. c+k+3
+            const uint32_t hi = k ? __builtin_amdgcn_alignbyte(e2, e1, k) : e1;   // taps at c+k+4 .. c+k+6
+            acc[k] = __builtin_amdgcn_udot4(lo, tap_lo, __builtin_amdgcn_udot4(hi, tap_hi, 0u, false), false);
+        }
+        *reinterpret_cast<uint2*>(&hp[r * DS_HP_P + c]) = make_uint2(acc[0] | (acc[1] << 16), acc[2] | (acc[3] << 16));
     }
-    __syncthreads();
     // ---- steered BRIEF (src/ORBextractor.cc:107-147)
     const float factorPI = (float)(3.141592653589793238462643383279502884 / 180.f);
     const float ang_rad = angle * factorPI;
@@ -613,7 +623,6 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
         bits[rnd] = __ballot(val[0] < val[1]);
     }
     const size_t o = (size_t)(frame0 + f) * cap + idx;
-    if (!valid) return;
     if (lane < 4) {
         const unsigned long long v = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
         reinterpret_cast<unsigned long long*>(out_desc + o * 32)[lane] = v;
