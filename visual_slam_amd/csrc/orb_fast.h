@@ -16,8 +16,9 @@
 //                     of the opposite ring pairs (N,S) and (E,W), one member that differs from the
 //                     centre by more than t with the same sign. Two pixels at a time are tested
 //                     with packed 16-bit ops (v_perm_b32, v_pk_sub/min/max_i16) straight from
-//                     registers: the rows of a five-row step are loaded together (11 loads
-//                     in flight per lane), the step is fully unrolled, no shuffles. Straight
+//                     registers: the rows of a five-row step are loaded together (11
+//                     coalesced dword loads in flight per lane, neighbour dwords by DPP wave
+//                     shifts), the step is fully unrolled. Straight
 //                     edges fail this test; the survivors of a step are compacted into a
 //                     per-wave queue with one wave prefix sum. The loaded rows are also copied
 //                     into an image tile in LDS.
@@ -79,13 +80,12 @@ __device__ __forceinline__ int fast_score16(int v, const int (&p)[16]) {
 #define FT_COLS 248        // output columns per tile (62 lanes x 4; lanes 0 and 63 are halo)
 #define FT_ROWS 32         // rows per tile
 #define FT_GROUP 5         // rows per unrolled sieve step
-#define FT_P 256           // LDS row pitch of map and image tile (tile column xl <-> level x xs - 4 + xl)
+#define FT_P 260           // LDS row pitch of map and image tile (tile column xl <-> level x xs - 4 + xl);
+                           // 65 dwords: pixels of one column in consecutive rows fall into different banks
 #define FT_MAP_ROWS 34     // tile rows -1 .. 32
 #define FT_IMG_ROWS 40     // tile rows -4 .. 35
 #define FT_QUEUE 256       // compaction window per wave
 #define FT_SEGCAP 768      // output segment of one wave: 8 rows x 248 columns after NMS hold < 700 survivors
-
-struct __attribute__((packed, aligned(4))) Row12 { uint32_t a, b, c; };
 
 // Inclusive prefix sum over the 64 lanes with DPP row shifts and row broadcasts.
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
@@ -108,6 +108,24 @@ __device__ __forceinline__ void fast_fill_queue(uint32_t bits, int first, int ba
         bits &= bits - 1;
         if (idx >= 0 && idx < FT_QUEUE) queue[idx] = (uint16_t)((4 * lane + (b & 3)) | ((row0 + (b >> 2)) << 8));
         idx++;
+    }
+}
+
+// The sieve's verdict words: acc0 bit 15-j / 31-j <-> row j, pixel 0 / 1 of the lane's group, acc1
+// the same for pixels 2 / 3. Same numbering and queue format as fast_fill_queue.
+__device__ __forceinline__ void fast_fill_sieve(uint32_t acc0, uint32_t acc1, int first, int base, int lane, int row0, uint16_t* queue) {
+    int idx = first - base;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        uint32_t bits = p ? acc1 : acc0;
+        while (bits) {
+            const int b = __ffs(bits) - 1;
+            bits &= bits - 1;
+            const int odd = b >> 4;
+            const int j = (odd ? 31 : 15) - b;
+            if (idx >= 0 && idx < FT_QUEUE) queue[idx] = (uint16_t)((4 * lane + 2 * p + odd) | ((row0 + j) << 8));
+            idx++;
+        }
     }
 }
 
@@ -150,7 +168,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
     const uint8_t* plane = pyr + g.pyr_off + (size_t)f * g.plane_bytes;
     // map row m <-> level row y0 - 1 + m; image tile row t <-> level row y0 - 4 + t
 
-    for (int i = tid; i < FT_MAP_ROWS * FT_P / 16; i += 256) reinterpret_cast<uint4*>(s_map)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < FT_MAP_ROWS * FT_P / 8; i += 256) reinterpret_cast<uint2*>(s_map)[i] = make_uint2(0, 0);
 
     // ---- sieve: map rows m0 .. m0+nrows-1 of this wave (9, 9, 8, 8 rows), five rows per step
     const int m0 = wv < 2 ? 9 * wv : 2 + 8 * wv;
@@ -163,11 +181,13 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
         const int xl = 4 * lane + i;
         ok_bits |= (uint32_t)(xg + i >= ORB_EDGE && xg + i < x_hi && xl >= 3 && xl <= 252) << i;
     }
+    // the same as masks over the sieve's verdict words (low half: even pixel, high half: odd pixel)
+    const uint32_t ok_mask0 = ((ok_bits & 1) ? 0x0000FFFFu : 0u) | ((ok_bits & 2) ? 0xFFFF0000u : 0u);
+    const uint32_t ok_mask1 = ((ok_bits & 4) ? 0x0000FFFFu : 0u) | ((ok_bits & 8) ? 0xFFFF0000u : 0u);
     __syncthreads();                                           // map is zero
 
     uint16_t* queue = s_queue[wv];
-    const v2s thr = {(short)(min_th + 1), (short)(min_th + 1)};
-    const v2s zero = {0, 0};
+    const v2s thr = {(short)min_th, (short)min_th};
     const uint8_t* base = plane + (size_t)ORB_OY * g.pitch + (col - 4);
     const int y_last = g.h + ORB_EDGE - 1;                     // last row of the plane
 #pragma unroll 1
@@ -175,16 +195,18 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
         const int mg = m0 + FT_GROUP * grp;                    // first map row of this step
         const int rg = y0 - 1 + mg;                            // its level row
         const int nstep = min(FT_GROUP, nrows - FT_GROUP * grp);
+        // one coalesced dword per lane and row; the dwords left and right of it come from the
+        // neighbouring lanes (lane 0 / 63 get nothing useful there: their outer pixels are not scored)
         uint32_t ctr[FT_GROUP], lft[FT_GROUP], rgt[FT_GROUP], above[3], below[3];
 #pragma unroll
         for (int j = 0; j < FT_GROUP; j++) {
             const int y = rg + j;
-            if (col_ok && y <= y_last) {
-                const Row12 v = *reinterpret_cast<const Row12*>(base + (ptrdiff_t)y * g.pitch);
-                lft[j] = v.a; ctr[j] = v.b; rgt[j] = v.c;
-            } else {
-                lft[j] = ctr[j] = rgt[j] = 0;
-            }
+            ctr[j] = (col_ok && y <= y_last) ? *reinterpret_cast<const uint32_t*>(base + (ptrdiff_t)y * g.pitch + 4) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < FT_GROUP; j++) {
+            lft[j] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ctr[j], 0x138, 0xf, 0xf, false);   // wave_shr:1
+            rgt[j] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ctr[j], 0x130, 0xf, 0xf, false);   // wave_shl:1
         }
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -204,33 +226,42 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
 #pragma unroll
             for (int j = 0; j < FT_GROUP; j++) *reinterpret_cast<uint32_t*>(t + (3 + j) * FT_P) = ctr[j];
         }
-        uint32_t bits = 0;
+        // unpack the own dword of every loaded row once: pixels 0,1 and 2,3 as 16-bit halves
+        v2s ulo[FT_GROUP + 6], uhi[FT_GROUP + 6];              // index t <-> level row rg - 3 + t
+#pragma unroll
+        for (int t = 0; t < FT_GROUP + 6; t++) {
+            const uint32_t v = t < 3 ? above[t < 3 ? t : 0] : t < 3 + FT_GROUP ? ctr[t >= 3 && t < 3 + FT_GROUP ? t - 3 : 0] : below[t >= 3 + FT_GROUP ? t - 3 - FT_GROUP : 0];
+            ulo[t] = pick2<0>(v, v);
+            uhi[t] = pick2<2>(v, v);
+        }
+        // With N,S,E,W the ring pixels at distance 3: the centre c can only be a corner at
+        // threshold t if  c - max(min(N,S), min(E,W)) > t  (centre brighter than one of each
+        // pair) or  min(max(N,S), max(E,W)) - c > t  (darker). The sign bit of
+        // t - max(c - A, B - c) is the verdict; the bits of the 5 rows are collected in two
+        // words: acc0 bit 15-j / 31-j <-> row j, pixel 0 / 1; acc1 likewise for pixels 2 / 3.
+        uint32_t acc0 = 0, acc1 = 0;
 #pragma unroll
         for (int j = 0; j < FT_GROUP; j++) {
             const int r = rg + j;
             if (j >= nstep || r < ORB_EDGE || r >= y_hi) continue;   // wave-uniform
-            const uint32_t up = j >= 3 ? ctr[j >= 3 ? j - 3 : 0] : above[j < 3 ? j : 0];
-            const uint32_t dn = j + 3 < FT_GROUP ? ctr[j + 3 < FT_GROUP ? j + 3 : 0] : below[j + 3 >= FT_GROUP ? j + 3 - FT_GROUP : 0];
-            // pair 0 = pixels 0,1 (bytes 4,5 of [lft ctr rgt]); pair 1 = pixels 2,3 (bytes 6,7)
-            const v2s c0 = pick2<0>(ctr[j], ctr[j]), c1 = pick2<2>(ctr[j], ctr[j]);
-            const v2s n0 = c0 - pick2<0>(dn, dn), n1 = c1 - pick2<2>(dn, dn);               // ring 0  = (0,+3)
-            const v2s s0 = c0 - pick2<0>(up, up), s1 = c1 - pick2<2>(up, up);               // ring 8  = (0,-3)
-            const v2s e0 = c0 - pick2<3>(rgt[j], ctr[j]), e1 = c1 - pick2<1>(rgt[j], rgt[j]);   // ring 4  = (+3,0)
-            const v2s w0 = c0 - pick2<1>(ctr[j], lft[j]), w1 = c1 - pick2<3>(ctr[j], lft[j]);   // ring 12 = (-3,0)
-            const v2s t0 = pmax(pmin(pmax(n0, s0), pmax(e0, w0)), zero - pmax(pmin(n0, s0), pmin(e0, w0)));
-            const v2s t1 = pmax(pmin(pmax(n1, s1), pmax(e1, w1)), zero - pmax(pmin(n1, s1), pmin(e1, w1)));
-            // pixel passes iff its half of t is >= min_th + 1: sign bit of (t - (min_th+1)) clear
-            const uint32_t q0 = ~v2u(t0 - thr), q1 = ~v2u(t1 - thr);
-            const uint32_t pass = (((q0 >> 15) & 1) | ((q0 >> 30) & 2) | ((q1 >> 13) & 4) | ((q1 >> 28) & 8)) & ok_bits;
-            bits |= pass << (4 * j);
+            const v2s e0 = pick2<3>(rgt[j], ctr[j]), e1 = pick2<1>(rgt[j], rgt[j]);     // (+3, 0)
+            const v2s w0 = pick2<1>(ctr[j], lft[j]), w1 = pick2<3>(ctr[j], lft[j]);     // (-3, 0)
+            const v2s a0 = pmax(pmin(ulo[j + 6], ulo[j]), pmin(e0, w0)), b0 = pmin(pmax(ulo[j + 6], ulo[j]), pmax(e0, w0));
+            const v2s a1 = pmax(pmin(uhi[j + 6], uhi[j]), pmin(e1, w1)), b1 = pmin(pmax(uhi[j + 6], uhi[j]), pmax(e1, w1));
+            const v2s u0 = thr - pmax(ulo[j + 3] - a0, b0 - ulo[j + 3]);
+            const v2s u1 = thr - pmax(uhi[j + 3] - a1, b1 - uhi[j + 3]);
+            acc0 |= (v2u(u0) >> j) & (0x80008000u >> j);
+            acc1 |= (v2u(u1) >> j) & (0x80008000u >> j);
         }
+        acc0 &= ok_mask0;
+        acc1 &= ok_mask1;
         // exact scores of the survivors (their rings lie in tile rows this wave has just written)
-        if (__ballot(bits != 0)) {
-            const uint32_t cnt = __popc(bits);
+        if (__ballot((acc0 | acc1) != 0)) {
+            const uint32_t cnt = __popc(acc0) + __popc(acc1);
             const uint32_t incl = wave_scan_incl(cnt);
             const int total = (int)__shfl(incl, 63, 64);
             for (int wb = 0; wb < total; wb += FT_QUEUE) {
-                fast_fill_queue(bits, (int)(incl - cnt), wb, lane, mg, queue);
+                fast_fill_sieve(acc0, acc1, (int)(incl - cnt), wb, lane, mg, queue);
                 const int nw = min(FT_QUEUE, total - wb);
                 for (int q = 0; q < nw; q += 64) fast_score_queue(queue + q, min(64, nw - q), lane, s_img, min_th, s_map);
             }

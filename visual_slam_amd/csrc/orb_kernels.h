@@ -63,6 +63,8 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src,
 // ------------------------------------------------------------------------------------------------
 #define RS_RPT 4
 
+struct __attribute__((packed, aligned(4))) Row12 { uint32_t a, b, c; };
+
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, LevelGeom gs, LevelGeom gd,
                                                 const RsTab* __restrict__ tabs, int ndw) {
     const int c4 = blockIdx.x * 64 + threadIdx.x;
