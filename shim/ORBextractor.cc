@@ -1,0 +1,101 @@
+// ORB_SLAM2::ORBextractor on top of libORBhip (see shim/ORBextractor.h). Every method forwards to
+// the C ABI entry point that replaces the corresponding part of the reference's
+// src/ORBextractor.cc; no image processing happens on the host.
+#include "ORBextractor.h"
+
+#include <cassert>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "../include/orbhip.h"
+
+namespace ORB_SLAM2
+{
+
+static_assert(sizeof(cv::KeyPoint) == sizeof(orbhip_keypoint), "cv::KeyPoint must be the 28-byte record libORBhip writes");
+
+static void check(int rc, orbhip_extractor* h, const char* what)
+{
+    if (rc != ORBHIP_OK)
+        throw std::runtime_error(std::string("ORBextractor (libORBhip) ") + what + ": " + orbhip_strerror(rc) +
+                                 (h ? std::string(" - ") + orbhip_last_error(h) : std::string()));
+}
+
+// reference: src/ORBextractor.cc:410-470 (tables are computed inside orbhip_create)
+ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels,
+                           int _iniThFAST, int _minThFAST):
+    mpHandle(0), mbFetchPyramid(true), nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels),
+    iniThFAST(_iniThFAST), minThFAST(_minThFAST)
+{
+    orbhip_params p;
+    std::memset(&p, 0, sizeof(p));
+    p.nfeatures = _nfeatures; p.scale_factor = _scaleFactor; p.nlevels = _nlevels;
+    p.ini_th_fast = _iniThFAST; p.min_th_fast = _minThFAST;
+    const char* dev = std::getenv("ORBHIP_DEVICE");
+    p.device = dev ? std::atoi(dev) : 0;
+    const char* blur = std::getenv("ORBHIP_BLUR_VARIANT");
+    p.blur_variant = blur ? std::atoi(blur) : ORBHIP_BLUR_LEGACY;
+    p.max_batch = 1;
+    check(orbhip_create(&p, &mpHandle), 0, "create");
+    mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels);
+    mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
+    orbhip_get_scale_factors(mpHandle, mvScaleFactor.data());
+    orbhip_get_inverse_scale_factors(mpHandle, mvInvScaleFactor.data());
+    orbhip_get_scale_sigma_squares(mpHandle, mvLevelSigma2.data());
+    orbhip_get_inverse_scale_sigma_squares(mpHandle, mvInvLevelSigma2.data());
+    mvImagePyramid.resize(nlevels);
+}
+
+ORBextractor::~ORBextractor()
+{
+    if (mpHandle) orbhip_destroy(mpHandle);
+}
+
+// reference: src/ORBextractor.cc:1043-1105
+void ORBextractor::operator()( cv::InputArray _image, cv::InputArray _mask, std::vector<cv::KeyPoint>& _keypoints,
+                      cv::OutputArray _descriptors)
+{
+    (void)_mask;
+    if(_image.empty())
+        return;
+
+    cv::Mat image = _image.getMat();
+    assert(image.type() == CV_8UC1 );
+
+    const int cap = orbhip_max_keypoints(mpHandle);
+    std::vector<orbhip_keypoint> kps(cap);
+    std::vector<unsigned char> desc((size_t)cap * 32);
+    int n = 0;
+    check(orbhip_extract(mpHandle, image.data, image.cols, image.rows, image.step, kps.data(), cap, &n, desc.data()),
+          mpHandle, "extract");
+
+    if( n == 0 )
+        _descriptors.release();
+    else
+    {
+        _descriptors.create(n, 32, CV_8U);
+        cv::Mat descriptors = _descriptors.getMat();
+        for (int i = 0; i < n; i++)
+            std::memcpy(descriptors.ptr(i), &desc[(size_t)i * 32], 32);
+    }
+    _keypoints.resize(n);
+    if (n) std::memcpy(static_cast<void*>(_keypoints.data()), kps.data(), (size_t)n * sizeof(orbhip_keypoint));
+
+    // mvImagePyramid[l] is the inner ROI of a (w+38)x(h+38) buffer, as ComputePyramid builds it
+    // (src/ORBextractor.cc:1113-1115); Frame::ComputeStereoMatches slices it (src/Frame.cc:578,595).
+    if (mbFetchPyramid)
+    {
+        for (int level = 0; level < nlevels; ++level)
+        {
+            int w = 0, h = 0;
+            check(orbhip_pyramid_info(mpHandle, level, &w, &h), mpHandle, "pyramid_info");
+            cv::Mat temp(h + 38, w + 38, CV_8UC1);
+            check(orbhip_pyramid_copy(mpHandle, 0, level, temp.data, temp.step, 1), mpHandle, "pyramid_copy");
+            mvImagePyramid[level] = temp(cv::Rect(19, 19, w, h));
+        }
+    }
+}
+
+} //namespace ORB_SLAM

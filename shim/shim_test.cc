@@ -1,0 +1,76 @@
+// Exercises shim/ORBextractor.{h,cc} (built against mini_cv.h) on the GPU and checks it against
+// the CPU oracle through the class API the reference's Frame / Tracking use. Test program only.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "ORBextractor.h"
+#include "../oracle/orb_oracle.h"
+
+static unsigned lcg(unsigned& s) { s = s * 1664525u + 1013904223u; return s >> 8; }
+
+#define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+
+int main()
+{
+    const int W = 752, H = 480;
+    cv::Mat img(H, W, CV_8UC1);
+    unsigned seed = 7;
+    std::memset(img.data, 128, (size_t)W * H);
+    for (int k = 0; k < W * H / 600; k++) {
+        int x = (int)(lcg(seed) % W), y = (int)(lcg(seed) % H), w = 8 + (int)(lcg(seed) % 89), h = 8 + (int)(lcg(seed) % 89);
+        unsigned char g = (unsigned char)(lcg(seed) & 255);
+        for (int yy = y; yy < y + h && yy < H; yy++) std::memset(img.ptr(yy) + x, g, (size_t)((x + w < W ? x + w : W) - x));
+    }
+    ORB_SLAM2::ORBextractor ex(1200, 1.2f, 8, 20, 7);
+    CHECK(ex.GetLevels() == 8);
+    CHECK(ex.GetScaleFactor() == 1.2f);
+    std::vector<float> sf = ex.GetScaleFactors(), isf = ex.GetInverseScaleFactors(), s2 = ex.GetScaleSigmaSquares(), is2 = ex.GetInverseScaleSigmaSquares();
+    CHECK(sf.size() == 8 && isf.size() == 8 && s2.size() == 8 && is2.size() == 8);
+    for (int i = 0; i < 8; i++) { CHECK(isf[i] == 1.0f / sf[i]); CHECK(s2[i] == sf[i] * sf[i]); CHECK(is2[i] == 1.0f / s2[i]); }
+
+    std::vector<cv::KeyPoint> kps;
+    cv::Mat desc;
+    ex(img, cv::Mat(), kps, desc);
+    CHECK(kps.size() > 600 && desc.rows == (int)kps.size() && desc.cols == 32);
+
+    // oracle through its C interface
+    orbo_extractor* o = orbo_create(1200, 1.2f, 8, 20, 7, ORBO_BLUR_LEGACY, ORBO_TIE_CREATION_ORDER, ORBO_FMA_OFF);
+    std::vector<orbo_keypoint> okp(4096);
+    std::vector<unsigned char> odesc(4096 * 32);
+    int on = 0;
+    CHECK(orbo_extract(o, img.data, W, H, img.step, okp.data(), 4096, &on, odesc.data()) == 0);
+    CHECK(on == (int)kps.size());
+    int desc_bad = 0;
+    for (int i = 0; i < on; i++) {
+        CHECK(kps[i].pt.x == okp[i].x && kps[i].pt.y == okp[i].y && kps[i].octave == okp[i].octave);
+        CHECK(kps[i].response == okp[i].response && kps[i].size == okp[i].size && kps[i].class_id == -1);
+        float da = kps[i].angle - okp[i].angle; if (da < 0) da = -da;
+        CHECK(da <= 1e-3f);
+        desc_bad += std::memcmp(desc.ptr(i), &odesc[(size_t)i * 32], 32) != 0;
+    }
+    CHECK(desc_bad * 1000 <= on);
+    // mvImagePyramid: ROI inside a bordered buffer, REFLECT_101 border, pixels equal to the oracle's
+    for (int l = 0; l < 8; l++) {
+        const cv::Mat& m = ex.mvImagePyramid[l];
+        int w = 0, h = 0;
+        orbo_level_size(o, l, &w, &h);
+        CHECK(m.cols == w && m.rows == h && (int)m.step == w + 38);
+        std::vector<unsigned char> ref((size_t)(w + 38) * (h + 38));
+        orbo_level_copy(o, l, ref.data(), (size_t)(w + 38), 1);
+        CHECK(std::memcmp(m.data - 19 * m.step - 19, ref.data(), ref.size()) == 0);
+        CHECK(m.ptr(5)[-3] == m.ptr(5)[3] && m.ptr(-2)[7] == m.ptr(2)[7]);
+    }
+    // empty input leaves the outputs untouched; second call replaces them
+    std::vector<cv::KeyPoint> keep = kps;
+    ex(cv::Mat(), cv::Mat(), kps, desc);
+    CHECK(kps.size() == keep.size());
+    cv::Mat flat(H, W, CV_8UC1);
+    std::memset(flat.data, 90, (size_t)W * H);
+    ex(flat, cv::Mat(), kps, desc);
+    CHECK(kps.empty() && desc.empty());
+    orbo_destroy(o);
+    std::printf("shim ok: %d keypoints, %d descriptor rows differ\n", on, desc_bad);
+    return 0;
+}
