@@ -72,6 +72,20 @@ def algorithmic_bytes(w, h, scale, levels, n_out):
     return parts, sum(parts.values())
 
 
+def profiled_traffic(kernel, frames):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary
+    (profiles/*_traffic.json, FETCH_SIZE/WRITE_SIZE passes), scaled to `frames` per launch."""
+    files = sorted((ROOT / "profiles").glob("*_traffic.json"))
+    if not files:
+        return None, None
+    try:
+        t = json.loads(files[-1].read_text())
+        k = t["kernels"][kernel]
+        return int(k["hbm_bytes_per_launch"] * frames / t["frames_per_launch"]), files[-1].name
+    except (KeyError, ValueError):
+        return None, None
+
+
 def make_batch_on_device(torch, kind, w, h, nframes, device, nbase=16):
     """nbase host-generated frames, expanded on the device by distinct circular shifts."""
     from visual_slam_amd import synth
@@ -168,8 +182,10 @@ def main():
         k_bytes_per_launch = parts[kname] * B * prof_steps / max(k_launches, 1)
         k_avg_s = k_ms * 1e-3 / max(k_launches, 1)
         achieved = k_bytes_per_launch / k_avg_s / 1e9
+        frames_per_launch = min(B, args.max_batch or 64)
+        traffic, traffic_src = profiled_traffic(kname, frames_per_launch)
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": int(k_bytes_per_launch), "avg_launch_ms": round(k_avg_s * 1e3, 4),
                     "whole_path_bytes_per_frame": int(total_bytes),
                     "whole_path_frac": round(fps / world * total_bytes / 1e9 / HBM_PEAK_GBS, 4),
