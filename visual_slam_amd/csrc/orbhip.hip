@@ -336,7 +336,7 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || p->device < 0 || p->device >= ndev) return ORBHIP_ERR_NO_DEVICE;
     orbhip_extractor* e = new orbhip_extractor;
     e->prm = *p;
-    if (e->prm.max_batch < 1) e->prm.max_batch = 64;
+    if (e->prm.max_batch < 1) e->prm.max_batch = 256;
     e->device = p->device;
     const int nl = p->nlevels;
     // src/ORBextractor.cc:412-431 (scaleFactor is a double member initialised from the float argument)
@@ -403,7 +403,11 @@ int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int 
     if (row_stride < (size_t)width) return ORBHIP_ERR_ARG;
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
-    const int chunk = std::min(nframes, e->prm.max_batch);
+    // frames per pass: max_batch, but keep the workspaces (about 20 bytes per input pixel and frame:
+    // pyramid planes, FAST output segments, quadtree keys) under ~24 GB
+    const double ws_per_frame = 20.0 * (double)width * (double)height;
+    const int ws_limit = std::max(1, (int)(24e9 / ws_per_frame));
+    const int chunk = std::min(nframes, std::min(e->prm.max_batch, ws_limit));
     if (e->plan_w != width || e->plan_h != height || e->plan_frames < chunk) {
         // a new plan frees the old workspaces: nothing may still be running on them
         HIP_TRY(e, hipDeviceSynchronize());
