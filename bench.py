@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--kind", default="blocks", choices=["blocks", "noise", "lowc"])
     ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--host-fed", action="store_true", help="also time the PCIe-inclusive host-buffer entry point")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for the barrier / max-time reduction")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses GPU 0 (use with --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -123,12 +125,17 @@ def main():
         sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (libORBhip has no CPU path)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     w, h, nfeat, scale, levels, ini_th, min_th = WORKLOADS[args.workload]
     ex = orbhip.ORBextractor(nfeat, scale, levels, ini_th, min_th, device=local_rank, max_batch=args.max_batch)
@@ -160,7 +167,7 @@ def main():
     dt = time.perf_counter() - t0
     ex.synchronize()   # raises on a deferred capacity error
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     fps = world * B * args.steps / dt

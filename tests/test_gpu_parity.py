@@ -20,6 +20,10 @@ CONFIGS = {
     "C4_1080p": (1920, 1080, 2000, 1.2, 8, 20, 7),
     "odd_small": (333, 211, 500, 1.2, 8, 20, 7),
     "kitti_th12": (1241, 376, 2000, 1.2, 8, 12, 7),
+    "C5_4k_deep": (3840, 2160, 8000, 1.1, 12, 20, 7),
+    "mono_init_2x": (640, 480, 2000, 1.2, 8, 20, 7),     # monocular initialisation uses 2*nFeatures (src/Tracking.cc:123)
+    "scale_2_0": (800, 600, 800, 2.0, 4, 20, 7),
+    "one_level": (320, 240, 300, 1.2, 1, 20, 7),
 }
 
 
@@ -55,11 +59,11 @@ def test_stages_and_outputs(mods, name, kind):
     print(name, kind, {k: v for k, v in r.items() if k != "desc_bad"})
 
 
-@pytest.mark.parametrize("name", ["C4_1080p", "kitti_th12"])
+@pytest.mark.parametrize("name", ["C4_1080p", "kitti_th12", "C5_4k_deep", "mono_init_2x", "scale_2_0", "one_level"])
 def test_outputs_large(mods, name):
     cfg = CONFIGS[name]
     g, o = _pair(mods, cfg)
-    for kind in ("blocks", "noise"):
+    for kind in (("blocks",) if name == "C5_4k_deep" else ("blocks", "noise")):
         img = synth.frame(kind, cfg[0], cfg[1], 1)
         gkp, gdesc = g(img, fetch_pyramid=False)
         okp, odesc = o.extract(img)
@@ -79,6 +83,36 @@ def test_const_and_empty(mods):
     with pytest.raises(orbhip.OrbHipError) as ei:
         g(np.zeros((200, 70), np.uint8))   # portrait strip: the reference divides by zero (nIni == 0)
     assert ei.value.code == orbhip.ERR_GEOMETRY
+
+
+def test_fixedpoint_blur_variant(mods):
+    orbhip, O = mods
+    img = synth.frame("blocks", 752, 480, 5)
+    g = orbhip.ORBextractor(1200, 1.2, 8, 20, 7, blur_variant=orbhip.BLUR_FIXEDPOINT)
+    o = O.OracleExtractor(1200, 1.2, 8, 20, 7, blur_variant=O.BLUR_FIXEDPOINT)
+    gkp, gdesc = g(img)
+    okp, odesc = o.extract(img)
+    r = compare_outputs(gkp, gdesc, okp, odesc)
+    assert r["desc_exact"] >= DESC_MIN_EXACT, r
+    legacy = orbhip.ORBextractor(1200, 1.2, 8, 20, 7)(img)[1]
+    assert np.array_equal(legacy.shape, gdesc.shape) and not np.array_equal(legacy, gdesc)   # the variant matters
+
+
+def test_strided_input_and_stereo_pair_batch(mods):
+    orbhip, O = mods
+    big = synth.frame("blocks", 800, 500, 9)
+    roi = big[10:490, 24:776]                       # 752x480 view with a row stride of 800
+    g = orbhip.ORBextractor(1200, 1.2, 8, 20, 7)
+    o = O.OracleExtractor(1200, 1.2, 8, 20, 7)
+    kp, desc = g(roi)
+    okp, odesc = o.extract(np.ascontiguousarray(roi))
+    assert compare_outputs(kp, desc, okp, odesc)["desc_exact"] >= DESC_MIN_EXACT
+    pair = np.stack([synth.frame("blocks", 752, 480, 30), synth.frame("blocks", 752, 480, 31)])
+    res = g.extract_batch(pair)
+    for i in range(2):
+        okp, odesc = o.extract(pair[i])
+        assert compare_outputs(res[i][0], res[i][1], okp, odesc)["desc_exact"] >= DESC_MIN_EXACT
+        assert np.array_equal(g.pyramid_level(3, frame=i), o.level(3))
 
 
 def test_batch_matches_single(mods):
