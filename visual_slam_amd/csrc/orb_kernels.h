@@ -23,30 +23,43 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // Level 0: copy of the input with the 19-px REFLECT_101 border. One thread writes 16 bytes of one
 // row; groups that lie inside the image and are 16-byte aligned in the source move as one dwordx4.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src, size_t row_stride,
-                                                size_t frame_stride, uint8_t* __restrict__ pyr,
-                                                LevelGeom g, int n16, int src_aligned16) {
-    const int c16 = blockIdx.x * 64 + threadIdx.x;
+// k_level0_interior: groups [g_lo, g_hi) of every row lie inside the image and the source is 16-byte
+// aligned. k_level0_edges: the remaining groups of a row (nb of them: those below skip_lo and from
+// skip_hi on), one thread per (row, group), reflecting byte path.
+__global__ __launch_bounds__(256) void k_level0_interior(const uint8_t* __restrict__ src, size_t row_stride,
+                                                         size_t frame_stride, uint8_t* __restrict__ pyr,
+                                                         LevelGeom g, int g_lo, int g_hi) {
+    const int c16 = g_lo + blockIdx.x * 64 + threadIdx.x;
     const int r = blockIdx.y * 4 + threadIdx.y;
     const int f = blockIdx.z;
-    if (c16 >= n16 || r >= g.rows) return;
+    if (c16 >= g_hi || r >= g.rows) return;
+    int sy = r - ORB_OY;
+    sy = sy < 0 ? -sy : (sy >= g.h ? 2 * (g.h - 1) - sy : sy);     // the border is narrower than the image
+    const uint8_t* S = src + (size_t)f * frame_stride + (size_t)sy * row_stride;
+    uint8_t* D = pyr + g.pyr_off + (size_t)f * g.plane_bytes + (size_t)r * g.pitch;
+    reinterpret_cast<uint4*>(D)[c16] = *reinterpret_cast<const uint4*>(S + (c16 * 16 - ORB_OX));
+}
+
+__global__ __launch_bounds__(256) void k_level0_edges(const uint8_t* __restrict__ src, size_t row_stride,
+                                                      size_t frame_stride, uint8_t* __restrict__ pyr,
+                                                      LevelGeom g, int nb, int skip_lo, int skip_hi) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int f = blockIdx.y;
+    const int r = i / nb;
+    if (r >= g.rows) return;
+    int c16 = i - r * nb;
+    if (c16 >= skip_lo) c16 += skip_hi - skip_lo;
     const uint8_t* S = src + (size_t)f * frame_stride + (size_t)reflect101(r - ORB_OY, g.h) * row_stride;
     const int x0 = c16 * 16 - ORB_OX;
-    uint4 out;
-    if (src_aligned16 && x0 >= 0 && x0 + 16 <= g.w) {
-        out = *reinterpret_cast<const uint4*>(S + x0);
-    } else {
-        uint32_t o[4];
+    uint32_t o[4];
 #pragma unroll
-        for (int d = 0; d < 4; d++) {
-            o[d] = 0;
+    for (int d = 0; d < 4; d++) {
+        o[d] = 0;
 #pragma unroll
-            for (int b = 0; b < 4; b++) o[d] |= (uint32_t)S[reflect101(x0 + 4 * d + b, g.w)] << (8 * b);
-        }
-        out = make_uint4(o[0], o[1], o[2], o[3]);
+        for (int b = 0; b < 4; b++) o[d] |= (uint32_t)S[reflect101(x0 + 4 * d + b, g.w)] << (8 * b);
     }
     uint8_t* D = pyr + g.pyr_off + (size_t)f * g.plane_bytes + (size_t)r * g.pitch;
-    reinterpret_cast<uint4*>(D)[c16] = out;
+    reinterpret_cast<uint4*>(D)[c16] = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -200,7 +213,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
                                                          int* __restrict__ lvl_cnt,
                                                          int* __restrict__ status) {
     extern __shared__ __align__(16) uint32_t smem[];
-    __shared__ uint32_t s_tmp[8];
+    __shared__ uint32_t s_tmp[QT_THREADS / 64];
     __shared__ uint32_t s_red[4];
     __shared__ int s_nkeys;
     const int tid = threadIdx.x;
@@ -505,6 +518,36 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {   // cv::fas
     return a;
 }
 
+// cosf / sinf of an angle in [0, 2*pi] as correctly rounded floats: evaluated in double (argument
+// reduced by multiples of pi/2 held as a two-term constant, then the classic degree-13 / degree-14
+// minimax kernels on [-pi/4, pi/4], error ~1e-16) and rounded once. libm's float routines return
+// the correctly rounded value in all but vanishingly rare cases, so this matches them.
+__device__ __forceinline__ void sincos_rounded(float x, float* c_out, float* s_out) {
+    const double xd = (double)x;
+    const double kf = rint(xd * 0.63661977236758134308);
+    const int k = (int)kf;
+    double r = fma(-kf, 1.57079632679489655800e+00, xd);
+    r = fma(-kf, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    const double sp = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                                  2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                                    8.33333333332248946124e-03), -1.66666666666666324348e-01);
+    const double sn = fma(r * z, sp, r);
+    const double cp = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                                  -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                                    -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double cs = fma(z * z, cp, fma(z, -0.5, 1.0));
+    double c, s;
+    switch (k & 3) {
+        case 0: c = cs; s = sn; break;
+        case 1: c = -sn; s = cs; break;
+        case 2: c = -cs; s = -sn; break;
+        default: c = sn; s = -cs; break;
+    }
+    *c_out = (float)c;
+    *s_out = (float)s;
+}
+
 __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ plan,
                                                   const uint8_t* __restrict__ pyr,
                                                   const LevelKp* __restrict__ lvl_kp,
@@ -598,7 +641,8 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     // ---- steered BRIEF (src/ORBextractor.cc:107-147)
     const float factorPI = (float)(3.141592653589793238462643383279502884 / 180.f);
     const float ang_rad = angle * factorPI;
-    const float a = (float)cos((double)ang_rad), b = (float)sin((double)ang_rad);
+    float a, b;                                   // cosf(ang_rad), sinf(ang_rad)
+    sincos_rounded(ang_rad, &a, &b);
     const int wv4 = g.w & ~3;
     const int ties_even = plan->blur_ties_even;
     unsigned long long bits[4];

@@ -266,8 +266,19 @@ int run_pass(orbhip_extractor* e, hipStream_t s, const uint8_t* d_imgs, int fram
         const LevelGeom& g = P.lv[0];
         const int n16 = (ORB_OX + g.w + ORB_EDGE + 15) / 16;
         const int aligned16 = ((uintptr_t)d_imgs % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0);
-        hipLaunchKernelGGL(k_level0, dim3((n16 + 63) / 64, (g.rows + 3) / 4, frames), blk2, 0, s,
-                           d_imgs, row_stride, frame_stride, e->d_pyr, g, n16, aligned16);
+        // 16-byte groups [i_lo, i_hi) lie inside the image: straight dwordx4 copies when the
+        // source is aligned; the groups that touch the border go through the reflecting byte path
+        const int i_lo = ORB_OX / 16, i_hi = (ORB_OX + g.w) / 16;
+        if (aligned16 && i_hi > i_lo && g.h > ORB_EDGE && g.w > ORB_OX) {
+            hipLaunchKernelGGL(k_level0_interior, dim3((i_hi - i_lo + 63) / 64, (g.rows + 3) / 4, frames), blk2, 0, s,
+                               d_imgs, row_stride, frame_stride, e->d_pyr, g, i_lo, i_hi);
+            const int nb = n16 - (i_hi - i_lo);
+            hipLaunchKernelGGL(k_level0_edges, dim3((g.rows * nb + 255) / 256, frames), dim3(256), 0, s,
+                               d_imgs, row_stride, frame_stride, e->d_pyr, g, nb, i_lo, i_hi);
+        } else {
+            hipLaunchKernelGGL(k_level0_edges, dim3((g.rows * n16 + 255) / 256, frames), dim3(256), 0, s,
+                               d_imgs, row_stride, frame_stride, e->d_pyr, g, n16, n16, n16);
+        }
     }
     for (int l = 1; l < nl; l++) {
         SpanGuard t(e, s, KC_RESIZE);
