@@ -113,7 +113,8 @@ __device__ __forceinline__ void fast_fill_queue(uint32_t bits, int first, int ba
 
 // The sieve's verdict words: acc0 bit 15-j / 31-j <-> row j, pixel 0 / 1 of the lane's group, acc1
 // the same for pixels 2 / 3. Same numbering and queue format as fast_fill_queue.
-__device__ __forceinline__ void fast_fill_sieve(uint32_t acc0, uint32_t acc1, int first, int base, int lane, int row0, uint16_t* queue) {
+// Queue slots below `lo` hold entries of an earlier step that are still waiting to be scored.
+__device__ __forceinline__ void fast_fill_sieve(uint32_t acc0, uint32_t acc1, int first, int base, int lo, int lane, int row0, uint16_t* queue) {
     int idx = first - base;
 #pragma unroll
     for (int p = 0; p < 2; p++) {
@@ -123,7 +124,7 @@ __device__ __forceinline__ void fast_fill_sieve(uint32_t acc0, uint32_t acc1, in
             bits &= bits - 1;
             const int odd = b >> 4;
             const int j = (odd ? 31 : 15) - b;
-            if (idx >= 0 && idx < FT_QUEUE) queue[idx] = (uint16_t)((4 * lane + 2 * p + odd) | ((row0 + j) << 8));
+            if (idx >= lo && idx < FT_QUEUE) queue[idx] = (uint16_t)((4 * lane + 2 * p + odd) | ((row0 + j) << 8));
             idx++;
         }
     }
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
     const v2s thr = {(short)min_th, (short)min_th};
     const uint8_t* base = plane + (size_t)ORB_OY * g.pitch + (col - 4);
     const int y_last = g.h + ORB_EDGE - 1;                     // last row of the plane
+    int pending = 0;                                           // queued pixels not scored yet (wave-uniform, < 64 between steps)
 #pragma unroll 1
     for (int grp = 0; grp < 2; grp++) {
         const int mg = m0 + FT_GROUP * grp;                    // first map row of this step
@@ -256,17 +258,27 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
         acc0 &= ok_mask0;
         acc1 &= ok_mask1;
         // exact scores of the survivors (their rings lie in tile rows this wave has just written)
+        // Only full batches of 64 are scored here; the remainder waits in the queue for the next step.
         if (__ballot((acc0 | acc1) != 0)) {
             const uint32_t cnt = __popc(acc0) + __popc(acc1);
             const uint32_t incl = wave_scan_incl(cnt);
             const int total = (int)__shfl(incl, 63, 64);
-            for (int wb = 0; wb < total; wb += FT_QUEUE) {
-                fast_fill_sieve(acc0, acc1, (int)(incl - cnt), wb, lane, mg, queue);
-                const int nw = min(FT_QUEUE, total - wb);
-                for (int q = 0; q < nw; q += 64) fast_score_queue(queue + q, min(64, nw - q), lane, s_img, min_th, s_map);
+            for (int wb = 0; wb < total;) {
+                const int room = FT_QUEUE - pending;
+                fast_fill_sieve(acc0, acc1, (int)(incl - cnt), wb - pending, pending, lane, mg, queue);
+                const int n = pending + min(room, total - wb);
+                const int nfull = n & ~63;
+                for (int q = 0; q < nfull; q += 64) fast_score_queue(queue + q, 64, lane, s_img, min_th, s_map);
+                pending = n - nfull;
+                if (nfull && lane < pending) {
+                    const uint16_t v = queue[nfull + lane];
+                    queue[lane] = v;
+                }
+                wb += room;
             }
         }
     }
+    if (pending) fast_score_queue(queue, pending, lane, s_img, min_th, s_map);
     __syncthreads();                                           // all scores of the tile are in the map
 
     // ---- non-maximum suppression inside the cell and emission, map rows 1+8*wv .. 8+8*wv

@@ -254,13 +254,21 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
             if (n <= 0) continue;
             const int base = atomicAdd(&s_nkeys, n);
             const uint2* src = sbase + (size_t)sidx * FT_SEGCAP;
-            for (int i = 0; i < n; i++) {
-                const uint2 e = src[i];
-                if (base + i < g.keys_cap) keys[base + i] = e;
-                if ((int)(e.y & 0xFF) >= ini_th) {
-                    const int x = e.x & 0xFFFF, y = e.x >> 16;
-                    const int c = ((y - 3) / g.hcell) * g.ncols + (x - 3) / g.wcell;
-                    atomicOr(&cellbits[c >> 5], 1u << (c & 31));
+            for (int i0 = 0; i0 < n; i0 += 4) {
+                uint2 e[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) e[u] = i0 + u < n ? src[i0 + u] : make_uint2(0u, 0u);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = i0 + u;
+                    if (i >= n) break;
+                    if (base + i < g.keys_cap) keys[base + i] = e[u];
+                    if ((int)(e[u].y & 0xFF) >= ini_th) {
+                        const int x = e[u].x & 0xFFFF, y = e[u].x >> 16;
+                        const int c = (int)__umulhi((uint32_t)(y - 3), g.hcell_magic) * g.ncols +
+                                      (int)__umulhi((uint32_t)(x - 3), g.wcell_magic);
+                        atomicOr(&cellbits[c >> 5], 1u << (c & 31));
+                    }
                 }
             }
         }
@@ -283,21 +291,31 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         q.cc[0][4 * i] = q.cc[0][4 * i + 1] = q.cc[0][4 * i + 2] = q.cc[0][4 * i + 3] = 0;
     }
     __syncthreads();
-    for (int k = tid; k < nkeys; k += QT_THREADS) {
-        uint2 e = keys[k];
-        const int x = e.x & 0xFFFF, y = e.x >> 16, s = e.y & 0xFF;
-        const int cx = (x - 3) / g.wcell, cy = (y - 3) / g.hcell;
-        uint32_t lab = ORB_DEAD_LABEL;
-        uint32_t qd = 0;
-        const int cell = cy * g.ncols + cx;
-        if (s >= ini_th || ((cellbits[cell >> 5] >> (cell & 31)) & 1) == 0) {
-            int root = (int)__fdiv_rn((float)x, g.hx);
-            root = min(max(root, 0), L - 1);
-            qd = qt_quadrant(q.box[0][2 * root], q.box[0][2 * root + 1], x, y);
-            atomicAdd(&q.cc[0][4 * root + qd], 1u);
-            lab = root;
+    for (int k0 = tid; k0 < nkeys; k0 += 4 * QT_THREADS) {
+        uint2 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int k = k0 + u * QT_THREADS;
+            e[u] = k < nkeys ? keys[k] : make_uint2(0u, 0u);
         }
-        keys[k].y = (uint32_t)s | (qd << 8) | (lab << 10);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (k0 + u * QT_THREADS >= nkeys) break;
+            const int x = e[u].x & 0xFFFF, y = e[u].x >> 16, s = e[u].y & 0xFF;
+            const int cx = (int)__umulhi((uint32_t)(x - 3), g.wcell_magic);
+            const int cy = (int)__umulhi((uint32_t)(y - 3), g.hcell_magic);
+            uint32_t lab = ORB_DEAD_LABEL;
+            uint32_t qd = 0;
+            const int cell = cy * g.ncols + cx;
+            if (s >= ini_th || ((cellbits[cell >> 5] >> (cell & 31)) & 1) == 0) {
+                int root = (int)__fdiv_rn((float)x, g.hx);
+                root = min(max(root, 0), L - 1);
+                qd = qt_quadrant(q.box[0][2 * root], q.box[0][2 * root + 1], x, y);
+                atomicAdd(&q.cc[0][4 * root + qd], 1u);
+                lab = root;
+            }
+            keys[k0 + u * QT_THREADS].y = (uint32_t)s | (qd << 8) | (lab << 10);
+        }
     }
     __syncthreads();
     for (int i = tid; i < L; i += QT_THREADS)
@@ -429,32 +447,50 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         else if (mode == 1 && Lnew + 3 * to_expand > N) mode = 2;
         // ---- E. keys follow their nodes
         if (!done) {
-            for (int k = tid; k < nkeys; k += QT_THREADS) {
-                const uint2 e = keys[k];
-                const uint32_t lab = e.y >> 10;
-                if (lab == ORB_DEAD_LABEL) continue;
-                const uint32_t qd = (e.y >> 8) & 3;
-                const uint32_t nl = q.kord[lab] >= 0 ? q.cc[cur][4 * lab + qd] : q.surv[lab];
-                const int x = e.x & 0xFFFF, y = e.x >> 16;
-                const uint32_t nq = qt_quadrant(q.box[nxt][2 * nl], q.box[nxt][2 * nl + 1], x, y);
-                atomicAdd(&q.cc[nxt][4 * nl + nq], 1u);
-                keys[k].y = (e.y & 0xFF) | (nq << 8) | (nl << 10);
+            // four keys per thread and trip, loads first: the loop is bound by memory latency
+            for (int k0 = tid; k0 < nkeys; k0 += 4 * QT_THREADS) {
+                uint2 e[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int k = k0 + u * QT_THREADS;
+                    e[u] = k < nkeys ? keys[k] : make_uint2(0u, ORB_DEAD_LABEL << 10);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t lab = e[u].y >> 10;
+                    if (lab == ORB_DEAD_LABEL) continue;
+                    const uint32_t qd = (e[u].y >> 8) & 3;
+                    const uint32_t nl = q.kord[lab] >= 0 ? q.cc[cur][4 * lab + qd] : q.surv[lab];
+                    const int x = e[u].x & 0xFFFF, y = e[u].x >> 16;
+                    const uint32_t nq = qt_quadrant(q.box[nxt][2 * nl], q.box[nxt][2 * nl + 1], x, y);
+                    atomicAdd(&q.cc[nxt][4 * nl + nq], 1u);
+                    keys[k0 + u * QT_THREADS].y = (e[u].y & 0xFF) | (nq << 8) | (nl << 10);
+                }
             }
         } else {
             // ---- best response per node, first in candidate order on ties (src/ORBextractor.cc:744-760)
             for (int i = tid; i < Lnew; i += QT_THREADS) q.key64[i] = 0ull;
             __syncthreads();
-            for (int k = tid; k < nkeys; k += QT_THREADS) {
-                const uint2 e = keys[k];
-                const uint32_t lab = e.y >> 10;
-                if (lab == ORB_DEAD_LABEL) continue;
-                const uint32_t qd = (e.y >> 8) & 3;
-                const uint32_t nl = q.kord[lab] >= 0 ? q.cc[cur][4 * lab + qd] : q.surv[lab];
-                const int x = e.x & 0xFFFF, y = e.x >> 16;
-                const int cx = (x - 3) / g.wcell, cy = (y - 3) / g.hcell;
-                const uint32_t ord = (uint32_t)(((cy * g.ncols + cx) * g.hcell + (y - 3 - cy * g.hcell)) * g.wcell +
-                                                (x - 3 - cx * g.wcell));
-                atomicMax(&q.key64[nl], ((unsigned long long)(e.y & 0xFF) << 32) | (0xFFFFFFFFu - ord));
+            for (int k0 = tid; k0 < nkeys; k0 += 4 * QT_THREADS) {
+                uint2 e[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int k = k0 + u * QT_THREADS;
+                    e[u] = k < nkeys ? keys[k] : make_uint2(0u, ORB_DEAD_LABEL << 10);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t lab = e[u].y >> 10;
+                    if (lab == ORB_DEAD_LABEL) continue;
+                    const uint32_t qd = (e[u].y >> 8) & 3;
+                    const uint32_t nl = q.kord[lab] >= 0 ? q.cc[cur][4 * lab + qd] : q.surv[lab];
+                    const int x = e[u].x & 0xFFFF, y = e[u].x >> 16;
+                    const int cx = (int)__umulhi((uint32_t)(x - 3), g.wcell_magic);
+                    const int cy = (int)__umulhi((uint32_t)(y - 3), g.hcell_magic);
+                    const uint32_t ord = (uint32_t)(((cy * g.ncols + cx) * g.hcell + (y - 3 - cy * g.hcell)) * g.wcell +
+                                                    (x - 3 - cx * g.wcell));
+                    atomicMax(&q.key64[nl], ((unsigned long long)(e[u].y & 0xFF) << 32) | (0xFFFFFFFFu - ord));
+                }
             }
         }
         __syncthreads();
