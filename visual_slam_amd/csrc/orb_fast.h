@@ -101,39 +101,37 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 // Every lane holds a bit set (bit b = row b/4 of the block, pixel b%4 of the lane's group). The
 // set bits of the wave are numbered lane by lane; those numbered base .. base+FT_QUEUE-1 are
 // written to the queue as  xl | (row0 + b/4) << 8.
-__device__ __forceinline__ void fast_fill_queue(uint32_t bits, int first, int base, int lane, int row0, uint16_t* queue) {
-    int idx = first - base;
+// CHECKED: only entries whose slot lies in [lo, FT_QUEUE) are written (the caller makes several
+// passes); otherwise the caller guarantees that all of them fit.
+template <bool CHECKED>
+__device__ __forceinline__ void fast_fill_queue(uint32_t bits, int idx, int lo, int lane, int row0, uint16_t* queue) {
+    const uint32_t base0 = (uint32_t)(4 * lane) | ((uint32_t)row0 << 8);
     while (bits) {
-        const int b = __ffs(bits) - 1;
+        const uint32_t b = (uint32_t)__ffs(bits) - 1;
         bits &= bits - 1;
-        if (idx >= 0 && idx < FT_QUEUE) queue[idx] = (uint16_t)((4 * lane + (b & 3)) | ((row0 + (b >> 2)) << 8));
+        if (!CHECKED || (idx >= lo && idx < FT_QUEUE)) queue[idx] = (uint16_t)(base0 + (b & 3) + ((b >> 2) << 8));
         idx++;
     }
 }
 
-// The sieve's verdict words: acc0 bit 15-j / 31-j <-> row j, pixel 0 / 1 of the lane's group, acc1
-// the same for pixels 2 / 3. Same numbering and queue format as fast_fill_queue.
-// Queue slots below `lo` hold entries of an earlier step that are still waiting to be scored.
-__device__ __forceinline__ void fast_fill_sieve(uint32_t acc0, uint32_t acc1, int first, int base, int lo, int lane, int row0, uint16_t* queue) {
-    int idx = first - base;
-#pragma unroll
-    for (int p = 0; p < 2; p++) {
-        uint32_t bits = p ? acc1 : acc0;
-        while (bits) {
-            const int b = __ffs(bits) - 1;
-            bits &= bits - 1;
-            const int odd = b >> 4;
-            const int j = (odd ? 31 : 15) - b;
-            if (idx >= lo && idx < FT_QUEUE) queue[idx] = (uint16_t)((4 * lane + 2 * p + odd) | ((row0 + j) << 8));
-            idx++;
-        }
+// The sieve's verdict word: bit 8*i + 7 - j <-> row j of the step, pixel i of the lane's group.
+// Same numbering and queue format as fast_fill_queue.
+template <bool CHECKED>
+__device__ __forceinline__ void fast_fill_sieve(uint32_t bits, int idx, int lo, int lane, int row0, uint16_t* queue) {
+    const uint32_t base0 = (uint32_t)(4 * lane) | ((uint32_t)row0 << 8);
+    while (bits) {
+        const uint32_t b = (uint32_t)__ffs(bits) - 1;
+        bits &= bits - 1;
+        if (!CHECKED || (idx >= lo && idx < FT_QUEUE)) queue[idx] = (uint16_t)(base0 + (b >> 3) + ((~b & 7) << 8));
+        idx++;
     }
 }
 
 // Scores `n` (<= 64) queued pixels, one per lane, from the LDS image tile into the tile map.
 // Queue entry: xl | map_row << 8; image tile row = map row + 3.
+// A pixel that reaches min_th also sets its bit in `occ` (8 words per map row, bit = tile column).
 __device__ __forceinline__ void fast_score_queue(const uint16_t* queue, int n, int lane, const uint8_t* img,
-                                                 int min_th, uint8_t* map) {
+                                                 int min_th, uint8_t* map, uint32_t* occ) {
     if (lane < n) {
         const int e = queue[lane];
         const int xl = e & 0xFF, row = e >> 8;
@@ -144,7 +142,10 @@ __device__ __forceinline__ void fast_score_queue(const uint16_t* queue, int n, i
         p[8] = c[-3 * FT_P];     p[9] = c[-3 * FT_P - 1];  p[10] = c[-2 * FT_P - 2]; p[11] = c[-FT_P - 3];
         p[12] = c[-3];           p[13] = c[FT_P - 3];      p[14] = c[2 * FT_P - 2];  p[15] = c[3 * FT_P - 1];
         const int s = fast_score16(c[0], p);
-        if (s >= min_th) map[row * FT_P + xl] = (uint8_t)s;
+        if (s >= min_th) {
+            map[row * FT_P + xl] = (uint8_t)s;
+            atomicOr(&occ[row * 8 + (xl >> 5)], 1u << (xl & 31));
+        }
     }
 }
 
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
     __shared__ __align__(16) uint8_t s_map[FT_MAP_ROWS * FT_P];
     __shared__ __align__(16) uint8_t s_img[FT_IMG_ROWS * FT_P];
     __shared__ uint16_t s_queue[4][FT_QUEUE];
+    __shared__ uint32_t s_occ[FT_MAP_ROWS * 8];                // bit per map pixel: it holds a score
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int f = blockIdx.z;
@@ -170,6 +172,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
     // map row m <-> level row y0 - 1 + m; image tile row t <-> level row y0 - 4 + t
 
     for (int i = tid; i < FT_MAP_ROWS * FT_P / 8; i += 256) reinterpret_cast<uint2*>(s_map)[i] = make_uint2(0, 0);
+    for (int i = tid; i < FT_MAP_ROWS * 8; i += 256) s_occ[i] = 0;
 
     // ---- sieve: map rows m0 .. m0+nrows-1 of this wave (9, 9, 8, 8 rows), five rows per step
     const int m0 = wv < 2 ? 9 * wv : 2 + 8 * wv;
@@ -182,9 +185,9 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
         const int xl = 4 * lane + i;
         ok_bits |= (uint32_t)(xg + i >= ORB_EDGE && xg + i < x_hi && xl >= 3 && xl <= 252) << i;
     }
-    // the same as masks over the sieve's verdict words (low half: even pixel, high half: odd pixel)
-    const uint32_t ok_mask0 = ((ok_bits & 1) ? 0x0000FFFFu : 0u) | ((ok_bits & 2) ? 0xFFFF0000u : 0u);
-    const uint32_t ok_mask1 = ((ok_bits & 4) ? 0x0000FFFFu : 0u) | ((ok_bits & 8) ? 0xFFFF0000u : 0u);
+    // the same as a mask over the sieve's verdict word (one byte per pixel)
+    const uint32_t ok_mask = ((ok_bits & 1) ? 0xFFu : 0u) | ((ok_bits & 2) ? 0xFF00u : 0u) |
+                             ((ok_bits & 4) ? 0xFF0000u : 0u) | ((ok_bits & 8) ? 0xFF000000u : 0u);
     __syncthreads();                                           // map is zero
 
     uint16_t* queue = s_queue[wv];
@@ -255,30 +258,38 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
             acc0 |= (v2u(u0) >> j) & (0x80008000u >> j);
             acc1 |= (v2u(u1) >> j) & (0x80008000u >> j);
         }
-        acc0 &= ok_mask0;
-        acc1 &= ok_mask1;
+        // one word: byte i = pixel i, bit 7-j of the byte = row j
+        const uint32_t verdict = __builtin_amdgcn_perm(acc1, acc0, 0x07050301u) & ok_mask;
         // exact scores of the survivors (their rings lie in tile rows this wave has just written)
         // Only full batches of 64 are scored here; the remainder waits in the queue for the next step.
-        if (__ballot((acc0 | acc1) != 0)) {
-            const uint32_t cnt = __popc(acc0) + __popc(acc1);
+        if (__ballot(verdict != 0)) {
+            const uint32_t cnt = __popc(verdict);
             const uint32_t incl = wave_scan_incl(cnt);
             const int total = (int)__shfl(incl, 63, 64);
-            for (int wb = 0; wb < total;) {
-                const int room = FT_QUEUE - pending;
-                fast_fill_sieve(acc0, acc1, (int)(incl - cnt), wb - pending, pending, lane, mg, queue);
-                const int n = pending + min(room, total - wb);
+            const int first = (int)(incl - cnt);
+            auto drain = [&](int n) {                          // n entries queued: score the full batches
                 const int nfull = n & ~63;
-                for (int q = 0; q < nfull; q += 64) fast_score_queue(queue + q, 64, lane, s_img, min_th, s_map);
+                for (int q = 0; q < nfull; q += 64) fast_score_queue(queue + q, 64, lane, s_img, min_th, s_map, s_occ);
                 pending = n - nfull;
                 if (nfull && lane < pending) {
                     const uint16_t v = queue[nfull + lane];
                     queue[lane] = v;
                 }
-                wb += room;
+            };
+            if (pending + total <= FT_QUEUE) {
+                fast_fill_sieve<false>(verdict, pending + first, 0, lane, mg, queue);
+                drain(pending + total);
+            } else {
+                for (int wb = 0; wb < total;) {
+                    const int room = FT_QUEUE - pending;
+                    fast_fill_sieve<true>(verdict, first - wb + pending, pending, lane, mg, queue);
+                    drain(pending + min(room, total - wb));
+                    wb += room;
+                }
             }
         }
     }
-    if (pending) fast_score_queue(queue, pending, lane, s_img, min_th, s_map);
+    if (pending) fast_score_queue(queue, pending, lane, s_img, min_th, s_map, s_occ);
     __syncthreads();                                           // all scores of the tile are in the map
 
     // ---- non-maximum suppression inside the cell and emission, map rows 1+8*wv .. 8+8*wv
@@ -288,20 +299,21 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
     const int mh = 1 + 8 * wv;
     uint32_t bits = 0;
     if (lane >= 1 && lane <= 62) {                             // lanes 0 and 63 hold neighbour columns only
+        // rows outside the detectable area were never scored: their bits are zero
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            if (y0 - 1 + mh + j >= y_hi) continue;
-            const uint32_t v = *reinterpret_cast<const uint32_t*>(&s_map[(mh + j) * FT_P + 4 * lane]);
-            const uint32_t nz = ((v & 0xFF) != 0) | (((v & 0xFF00) != 0) << 1) | (((v & 0xFF0000) != 0) << 2) | (((v >> 24) != 0) << 3);
-            bits |= nz << (4 * j);
+            const uint32_t v = s_occ[(mh + j) * 8 + (lane >> 3)];
+            bits |= ((v >> (4 * (lane & 7))) & 0xFu) << (4 * j);
         }
     }
     if (__ballot(bits != 0)) {
         const uint32_t cnt = __popc(bits);
         const uint32_t incl = wave_scan_incl(cnt);
         const int total = (int)__shfl(incl, 63, 64);
+        const int first = (int)(incl - cnt);
         for (int wb = 0; wb < total; wb += FT_QUEUE) {
-            fast_fill_queue(bits, (int)(incl - cnt), wb, lane, mh, queue);
+            if (total <= FT_QUEUE) fast_fill_queue<false>(bits, first, 0, lane, mh, queue);
+            else fast_fill_queue<true>(bits, first - wb, 0, lane, mh, queue);
             const int nw = min(FT_QUEUE, total - wb);
             for (int q = 0; q < nw; q += 64) {
                 bool keep = false;
