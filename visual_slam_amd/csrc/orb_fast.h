@@ -89,10 +89,10 @@ __device__ __forceinline__ int fast_score16(int v, const int (&p)[16]) {
 
 // Inclusive prefix sum over the 64 lanes with DPP row shifts and row broadcasts.
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1,3
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2,3
     return v;
@@ -160,7 +160,8 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
     __shared__ uint16_t s_queue[4][FT_QUEUE];
     __shared__ uint32_t s_occ[FT_MAP_ROWS * 8];                // bit per map pixel: it holds a score
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: row bookkeeping runs on the scalar unit
     const int f = blockIdx.z;
     const int xs = ORB_MINB + FT_COLS * (int)blockIdx.x;       // level x of the tile's first output column
     const int y0 = ORB_EDGE + FT_ROWS * (int)blockIdx.y;       // level y of the tile's first row
@@ -192,8 +193,14 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
 
     uint16_t* queue = s_queue[wv];
     const v2s thr = {(short)min_th, (short)min_th};
-    const uint8_t* base = plane + (size_t)ORB_OY * g.pitch + (col - 4);
     const int y_last = g.h + ORB_EDGE - 1;                     // last row of the plane
+    // The lane's dword of level row y (wave-uniform: scalar row address + per-lane column). Rows past
+    // the plane repeat the last row and lanes past its width read column 0: neither feeds a scored pixel.
+    const uint32_t coff = col_ok ? (uint32_t)col : 0u;
+    auto load_row = [&](int y) -> uint32_t {
+        const uint32_t off = (uint32_t)((ORB_OY + min(y, y_last)) * g.pitch) + coff;   // a plane is far below 4 GB
+        return *reinterpret_cast<const uint32_t*>(plane + off);
+    };
     int pending = 0;                                           // queued pixels not scored yet (wave-uniform, < 64 between steps)
 #pragma unroll 1
     for (int grp = 0; grp < 2; grp++) {
@@ -204,20 +211,16 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
         // neighbouring lanes (lane 0 / 63 get nothing useful there: their outer pixels are not scored)
         uint32_t ctr[FT_GROUP], lft[FT_GROUP], rgt[FT_GROUP], above[3], below[3];
 #pragma unroll
-        for (int j = 0; j < FT_GROUP; j++) {
-            const int y = rg + j;
-            ctr[j] = (col_ok && y <= y_last) ? *reinterpret_cast<const uint32_t*>(base + (ptrdiff_t)y * g.pitch + 4) : 0u;
-        }
+        for (int j = 0; j < FT_GROUP; j++) ctr[j] = load_row(rg + j);
 #pragma unroll
         for (int j = 0; j < FT_GROUP; j++) {
-            lft[j] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ctr[j], 0x138, 0xf, 0xf, false);   // wave_shr:1
-            rgt[j] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ctr[j], 0x130, 0xf, 0xf, false);   // wave_shl:1
+            lft[j] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ctr[j], 0x138, 0xf, 0xf, true);   // wave_shr:1
+            rgt[j] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ctr[j], 0x130, 0xf, 0xf, true);   // wave_shl:1
         }
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            const int ya = rg - 3 + j, yb = rg + FT_GROUP + j;
-            above[j] = col_ok ? *reinterpret_cast<const uint32_t*>(base + (ptrdiff_t)ya * g.pitch + 4) : 0u;
-            below[j] = (col_ok && yb <= y_last) ? *reinterpret_cast<const uint32_t*>(base + (ptrdiff_t)yb * g.pitch + 4) : 0u;
+            above[j] = load_row(rg - 3 + j);
+            below[j] = load_row(rg + FT_GROUP + j);
         }
         // copy what was loaded into the image tile (tile rows mg .. mg+10 = level rows rg-3 .. rg+7;
         // other steps and waves write identical bytes to the rows they share)
@@ -329,12 +332,13 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
                     const int yin = uy - (int)__umulhi((uint32_t)uy, g.hcell_magic) * g.hcell;
                     // neighbours in another cell (or outside the detectable area, where the map is 0) do not count
                     const bool l = xin > 0, r = xin < g.wcell - 1, u = yin > 0, d = yin < g.hcell - 1;
-                    int mx = 0;
-                    if (l) mx = c[-1];
-                    if (r) mx = max(mx, (int)c[1]);
-                    if (u) { mx = max(mx, (int)c[-FT_P]); if (l) mx = max(mx, (int)c[-FT_P - 1]); if (r) mx = max(mx, (int)c[-FT_P + 1]); }
-                    if (d) { mx = max(mx, (int)c[FT_P]); if (l) mx = max(mx, (int)c[FT_P - 1]); if (r) mx = max(mx, (int)c[FT_P + 1]); }
-                    keep = s > mx;
+                    // all eight reads are in range (the map has a one-pixel halo); issue them together
+                    const int nw_ = c[-FT_P - 1], n_ = c[-FT_P], ne_ = c[-FT_P + 1], w_ = c[-1], e_ = c[1];
+                    const int sw_ = c[FT_P - 1], s_ = c[FT_P], se_ = c[FT_P + 1];
+                    const int mu = max(max(l ? nw_ : 0, n_), r ? ne_ : 0);
+                    const int md = max(max(l ? sw_ : 0, s_), r ? se_ : 0);
+                    const int mc = max(l ? w_ : 0, r ? e_ : 0);
+                    keep = s > max(max(u ? mu : 0, d ? md : 0), mc);
                 }
                 const unsigned long long km = __ballot(keep);
                 if (keep) {
