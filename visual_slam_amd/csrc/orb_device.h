@@ -63,6 +63,9 @@ struct PlanDev {
     int blur_taps[4];                    // centre, +-1, +-2, +-3
     int blur_ties_even;                  // 1: legacy x86 column kernel (ties to even for x < (w & ~3))
     int umax[16];
+    // Byte weights of the orientation disc, one row of 32 bytes per |v| (byte i <-> u = i - 15):
+    // words 0..7 hold 1 where |u| <= umax[|v|], words 8..15 hold u + 15 there; 0 elsewhere.
+    uint32_t disc_w[16][16];
     LevelGeom lv[ORB_MAX_LEVELS];
 };
 

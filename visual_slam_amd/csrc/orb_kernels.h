@@ -593,7 +593,8 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
                                                   int cap, int frame0, int* __restrict__ status) {
     __shared__ __align__(16) uint8_t s_raw[4][DS_RAW_BYTES];
     __shared__ __align__(16) uint16_t s_hp[4][DS_HP_ENTRIES];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // everything per keypoint is wave-uniform
     const int f = blockIdx.y;
     const int idx = blockIdx.x * 4 + wv;
     const int nl = plan->nlevels;
@@ -622,35 +623,51 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     const int col0 = kx - 22 + ORB_OX;            // >= 29: keypoints are >= 19 px from the level edge
     const int colA = col0 & ~3, off = col0 & 3;
     uint8_t* raw = s_raw[wv];
-    for (int i = lane; i < 45 * 13; i += 64) {
-        const int r = i / 13, c = i - r * 13;
-        const uint32_t v = *reinterpret_cast<const uint32_t*>(P + (size_t)(ky - 22 + r + ORB_OY) * g.pitch + colA + c * 4);
-        *reinterpret_cast<uint32_t*>(&raw[r * DS_RAW_P + c * 4]) = v;
+    // disc weights of this lane's row for the orientation step below (loaded early)
+    const uint4* dwp = reinterpret_cast<const uint4*>(plan->disc_w[lane < 31 ? (lane < 15 ? 15 - lane : lane - 15) : 0]);
+    const uint4 dw0 = dwp[0], dw1 = dwp[1], dw2 = dwp[2], dw3 = dwp[3];
+    // (16 lanes per row, 13 of them active, 4 rows per trip: addresses advance by a constant)
+    {
+        const int sr = lane >> 4, sc = lane & 15;
+        uint32_t goff = (uint32_t)((ky - 22 + ORB_OY + sr) * g.pitch + colA + sc * 4);   // a plane is far below 4 GB
+        uint8_t* dst = &raw[sr * DS_RAW_P + sc * 4];
+        if (sc < 13) {
+#pragma unroll
+            for (int p = 0; p < 12; p++) {
+                if (4 * p + sr < 45) {
+                    const uint32_t v = *reinterpret_cast<const uint32_t*>(P + goff);
+                    *reinterpret_cast<uint32_t*>(dst + p * 4 * DS_RAW_P) = v;
+                }
+                goff += 4 * (uint32_t)g.pitch;
+            }
+        }
     }
     // ---- IC_Angle (src/ORBextractor.cc:77-104): integer moments over the 749-px disc. Lane = one
     // column u of one half of the disc; the disc is symmetric, so column u spans |v| <= umax[|u|].
     int m10 = 0, m01 = 0;
-    {
-        const int u = (lane & 31) - 15;           // column offset; lanes 31 and 63 idle
-        const int half = lane >> 5;               // 0: rows -15..0, 1: rows 1..15
-        if (u <= 15) {
-            const int lim = plan->umax[u < 0 ? -u : u];
-            const uint8_t* c0 = &raw[22 * DS_RAW_P + off + 22 + u];
-            int colsum = 0, vsum = 0;
-            if (half) {
-                for (int v = 1; v <= lim; v++) { const int I = c0[v * DS_RAW_P]; colsum += I; vsum += v * I; }
-            } else {
-                for (int v = 0; v <= lim; v++) { const int I = c0[-v * DS_RAW_P]; colsum += I; vsum -= v * I; }
-            }
-            m10 = u * colsum;
-            m01 = vsum;
-        }
+    if (lane < 31) {
+        // lane = row v of the disc: 32 bytes from u = -15 on, two byte dot products per dword
+        // (sum of I and sum of (u + 15) * I over |u| <= umax[|v|])
+        const int first = off + 7;                // byte of u = -15 in the staged row
+        const uint32_t* rw = reinterpret_cast<const uint32_t*>(&raw[(lane + 7) * DS_RAW_P]) + (first >> 2);
+        const uint32_t sh = first & 3;
+        uint32_t d[9];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            m10 += __shfl_xor(m10, o, 64);
-            m01 += __shfl_xor(m01, o, 64);
+        for (int k = 0; k < 9; k++) d[k] = rw[k];
+        const uint32_t w[16] = {dw0.x, dw0.y, dw0.z, dw0.w, dw1.x, dw1.y, dw1.z, dw1.w,
+                                dw2.x, dw2.y, dw2.z, dw2.w, dw3.x, dw3.y, dw3.z, dw3.w};
+        uint32_t s0 = 0, s1 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t e = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
+            s0 = __builtin_amdgcn_udot4(e, w[k], s0, false);
+            s1 = __builtin_amdgcn_udot4(e, w[8 + k], s1, false);
         }
+        m10 = (int)s1 - 15 * (int)s0;
+        m01 = (lane - 15) * (int)s0;
     }
+    m10 = __builtin_amdgcn_readlane((int)wave_scan_incl((uint32_t)m10), 63);
+    m01 = __builtin_amdgcn_readlane((int)wave_scan_incl((uint32_t)m01), 63);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     // ---- horizontal blur pass: hp[r][c] for rows ky-22..ky+22, columns kx-19..kx+19. A lane
     // produces 4 adjacent sums from 16 staged bytes with byte-aligned dword extracts and

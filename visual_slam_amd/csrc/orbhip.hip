@@ -145,6 +145,13 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames) {
     blur_taps(e->prm.blur_variant, P.blur_taps);
     P.blur_ties_even = e->prm.blur_variant == ORBHIP_BLUR_LEGACY;
     std::memcpy(P.umax, e->umax, sizeof(P.umax));
+    for (int a = 0; a < 16; a++)
+        for (int i = 0; i < 31; i++) {
+            const int u = i - 15;
+            if (std::abs(u) > e->umax[a]) continue;
+            P.disc_w[a][i >> 2] |= 1u << (8 * (i & 3));
+            P.disc_w[a][8 + (i >> 2)] |= (uint32_t)(u + 15) << (8 * (i & 3));
+        }
     size_t pyr_off = 0, keys_off = 0, seg_off = 0;
     int segc_off = 0, kp_off = 0, tab_off = 0;
     size_t max_qt_words = 0;
