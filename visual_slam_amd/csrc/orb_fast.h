@@ -328,8 +328,8 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
                     s = c[0];
                     x = xs - 4 + xl; y = y0 - 1 + m;
                     const int ux = x - ORB_EDGE, uy = y - ORB_EDGE;
-                    const int xin = ux - (int)__umulhi((uint32_t)ux, g.wcell_magic) * g.wcell;
-                    const int yin = uy - (int)__umulhi((uint32_t)uy, g.hcell_magic) * g.hcell;
+                    const int xin = ux - __mul24((int)__umulhi((uint32_t)ux, g.wcell_magic), g.wcell);
+                    const int yin = uy - __mul24((int)__umulhi((uint32_t)uy, g.hcell_magic), g.hcell);
                     // neighbours in another cell (or outside the detectable area, where the map is 0) do not count
                     const bool l = xin > 0, r = xin < g.wcell - 1, u = yin > 0, d = yin < g.hcell - 1;
                     // all eight reads are in range (the map has a one-pixel halo); issue them together

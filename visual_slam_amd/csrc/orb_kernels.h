@@ -81,7 +81,8 @@ struct __attribute__((packed, aligned(4))) Row12 { uint32_t a, b, c; };
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, LevelGeom gs, LevelGeom gd,
                                                 const RsTab* __restrict__ tabs, int ndw) {
     const int c4 = blockIdx.x * 64 + threadIdx.x;
-    const int r0 = (blockIdx.y * 4 + threadIdx.y) * RS_RPT;
+    // a wave = one value of threadIdx.y: rows, their tap entries and row addresses are wave-uniform
+    const int r0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * RS_RPT;
     const int f = blockIdx.z;
     if (c4 >= ndw || r0 >= gd.rows) return;
     // x side: the same for every row
@@ -100,13 +101,15 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, Level
         const uint32_t idx = (uint32_t)(hi[i] ? o - 4 : o);     // byte index inside the chosen dword pair
         sel[i] = idx | (0x0Cu << 8) | ((idx + 1) << 16) | (0x0Cu << 24);
     }
-    const uint8_t* S = pyr + gs.pyr_off + (size_t)f * gs.plane_bytes + (size_t)ORB_OY * gs.pitch + ORB_OX + base;
+    // uniform plane pointers + 32-bit (row, lane) offsets: a plane is far below 4 GB
+    const uint8_t* S = pyr + gs.pyr_off + (size_t)f * gs.plane_bytes + (size_t)ORB_OY * gs.pitch + ORB_OX;
+    const uint32_t lbase = (uint32_t)base;
     uint8_t* D = pyr + gd.pyr_off + (size_t)f * gd.plane_bytes;
     const RsTab* ytab = tabs + gd.ytab_off;
     int prev_row = -1;
     int hprev[4] = {0, 0, 0, 0};
     auto hpass = [&](int srow, int (&h)[4]) {
-        const Row12 v = *reinterpret_cast<const Row12*>(S + (size_t)srow * gs.pitch);
+        const Row12 v = *reinterpret_cast<const Row12*>(S + ((uint32_t)(srow * gs.pitch) + lbase));
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t p = __builtin_amdgcn_perm(hi[i] ? v.c : v.b, hi[i] ? v.b : v.a, sel[i]);   // tap0 | tap1 << 16
@@ -132,10 +135,11 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, Level
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             hprev[i] = h1[i];
-            const int v = (((b0 * h0[i]) >> 16) + ((b1 * h1[i]) >> 16) + 2) >> 2;     // <= 255 by construction
+            // 11-bit weight x 15-bit row value: the full-rate 24-bit multiply is exact
+            const int v = ((__mul24(b0, h0[i]) >> 16) + (__mul24(b1, h1[i]) >> 16) + 2) >> 2;     // <= 255 by construction
             out |= (uint32_t)v << (8 * i);
         }
-        reinterpret_cast<uint32_t*>(D + (size_t)r * gd.pitch)[c4] = out;
+        *reinterpret_cast<uint32_t*>(D + ((uint32_t)(r * gd.pitch) + 4u * (uint32_t)c4)) = out;
     }
 }
 
@@ -663,8 +667,8 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
             s0 = __builtin_amdgcn_udot4(e, w[k], s0, false);
             s1 = __builtin_amdgcn_udot4(e, w[8 + k], s1, false);
         }
-        m10 = (int)s1 - 15 * (int)s0;
-        m01 = (lane - 15) * (int)s0;
+        m10 = (int)s1 - __mul24(15, (int)s0);     // s0 <= 31 * 255: 24-bit multiplies are exact
+        m01 = __mul24(lane - 15, (int)s0);
     }
     m10 = __builtin_amdgcn_readlane((int)wave_scan_incl((uint32_t)m10), 63);
     m01 = __builtin_amdgcn_readlane((int)wave_scan_incl((uint32_t)m01), 63);
@@ -676,8 +680,9 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     const uint32_t tap_lo = (uint32_t)t3 | ((uint32_t)t2 << 8) | ((uint32_t)t1 << 16) | ((uint32_t)t0 << 24);
     const uint32_t tap_hi = (uint32_t)t1 | ((uint32_t)t2 << 8) | ((uint32_t)t3 << 16);
     uint16_t* hp = s_hp[wv];
-    for (int t = lane; t < 45 * 10; t += 64) {
-        const int r = t / 10, c = (t - r * 10) * 4;            // sums c..c+3 (column 39 is padding)
+    int hr = lane / 10, hc = lane - hr * 10;                   // item t = 10 * hr + hc; t += 64 <=> (hr, hc) += (6, 4)
+    for (int t = lane; t < 45 * 10; t += 64, hr += hc >= 6 ? 7 : 6, hc += hc >= 6 ? -6 : 4) {
+        const int r = hr, c = hc * 4;                          // sums c..c+3 (column 39 is padding)
         const uint32_t* rw = reinterpret_cast<const uint32_t*>(&raw[r * DS_RAW_P + c]);
         const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2], d3 = rw[3];
         const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, off), e1 = __builtin_amdgcn_alignbyte(d2, d1, off),
@@ -710,9 +715,10 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
             const float py = (float)(signed char)(pk >> (16 * e + 8));
             const int ry = (int)rintf(px * b + py * a);
             const int rx = (int)rintf(px * a - py * b);
-            const uint16_t* h = &hp[(ry + 22) * DS_HP_P + rx + 19];
-            const int acc = t0 * h[0] + t1 * (h[-DS_HP_P] + h[DS_HP_P]) + t2 * (h[-2 * DS_HP_P] + h[2 * DS_HP_P]) +
-                            t3 * (h[-3 * DS_HP_P] + h[3 * DS_HP_P]);
+            // taps < 2^6, row sums < 2^17: full-rate 24-bit multiplies are exact
+            const uint16_t* h = &hp[__mul24(ry + 22, DS_HP_P) + rx + 19];
+            const int acc = __mul24(t0, h[0]) + __mul24(t1, h[-DS_HP_P] + h[DS_HP_P]) +
+                            __mul24(t2, h[-2 * DS_HP_P] + h[2 * DS_HP_P]) + __mul24(t3, h[-3 * DS_HP_P] + h[3 * DS_HP_P]);
             int qv = acc >> 16;
             const int rem = acc & 0xFFFF;
             if (rem > 32768) qv++;
