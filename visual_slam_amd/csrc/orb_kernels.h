@@ -72,14 +72,17 @@ __global__ __launch_bounds__(256) void k_level0_edges(const uint8_t* __restrict_
 // lie inside 12 bytes starting at a 4-aligned offset (checked on the host), so one dwordx3 load
 // per source row feeds them; v_perm_b32 pulls the two taps of a pixel into 16-bit halves and
 // v_dot2_i32_i16 applies the two 11-bit weights. Consecutive output rows usually share a source
-// row; its horizontal pass is reused.
+// row; its horizontal pass is reused. A wave is short, so its time is set by memory latency: all
+// source rows of its RS_RPT output rows are requested before any arithmetic starts.
 // ------------------------------------------------------------------------------------------------
-#define RS_RPT 4
+#define RS_RPT 8
 
 struct __attribute__((packed, aligned(4))) Row12 { uint32_t a, b, c; };
 
-__global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, LevelGeom gs, LevelGeom gd,
-                                                const RsTab* __restrict__ tabs, int ndw) {
+// src / dst: plane of frame 0 of the source / destination level (different levels never overlap,
+// which lets the loads of all rows be issued before the first store).
+__global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                LevelGeom gs, LevelGeom gd, const RsTab* __restrict__ tabs, int ndw) {
     const int c4 = blockIdx.x * 64 + threadIdx.x;
     // a wave = one value of threadIdx.y: rows, their tap entries and row addresses are wave-uniform
     const int r0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * RS_RPT;
@@ -102,35 +105,43 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, Level
         sel[i] = idx | (0x0Cu << 8) | ((idx + 1) << 16) | (0x0Cu << 24);
     }
     // uniform plane pointers + 32-bit (row, lane) offsets: a plane is far below 4 GB
-    const uint8_t* S = pyr + gs.pyr_off + (size_t)f * gs.plane_bytes + (size_t)ORB_OY * gs.pitch + ORB_OX;
+    const uint8_t* S = src + (size_t)f * gs.plane_bytes + (size_t)ORB_OY * gs.pitch + ORB_OX;
     const uint32_t lbase = (uint32_t)base;
-    uint8_t* D = pyr + gd.pyr_off + (size_t)f * gd.plane_bytes;
+    uint8_t* D = dst + (size_t)f * gd.plane_bytes;
     const RsTab* ytab = tabs + gd.ytab_off;
-    int prev_row = -1;
-    int hprev[4] = {0, 0, 0, 0};
-    auto hpass = [&](int srow, int (&h)[4]) {
-        const Row12 v = *reinterpret_cast<const Row12*>(S + ((uint32_t)(srow * gs.pitch) + lbase));
+    // y taps of the wave's rows (scalar loads), then every source row it needs, then the arithmetic
+    RsTab ty[RS_RPT];
+#pragma unroll
+    for (int k = 0; k < RS_RPT; k++) ty[k] = ytab[min(r0 + k, gd.rows - 1)];
+    Row12 va[RS_RPT], vb[RS_RPT];
+#pragma unroll
+    for (int k = 0; k < RS_RPT; k++) {
+        // consecutive output rows usually share a source row: the upper row of k is the lower row of k-1
+        if (k == 0 || ty[k].s0 != ty[k - 1].s1)
+            va[k] = *reinterpret_cast<const Row12*>(S + ((uint32_t)((int)ty[k].s0 * gs.pitch) + lbase));
+        vb[k] = *reinterpret_cast<const Row12*>(S + ((uint32_t)((int)ty[k].s1 * gs.pitch) + lbase));
+    }
+    auto hpass = [&](const Row12& v, int (&h)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t p = __builtin_amdgcn_perm(hi[i] ? v.c : v.b, hi[i] ? v.b : v.a, sel[i]);   // tap0 | tap1 << 16
             h[i] = __builtin_amdgcn_sdot2(u2v(p), u2v(wgt[i]), 0, false) >> 4;
         }
     };
+    int hprev[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < RS_RPT; k++) {
         const int r = r0 + k;
         if (r >= gd.rows) break;
-        const RsTab ty = ytab[r];
         int h0[4], h1[4];
-        if ((int)ty.s0 == prev_row) {
+        if (k > 0 && ty[k].s0 == ty[k - 1].s1) {
 #pragma unroll
             for (int i = 0; i < 4; i++) h0[i] = hprev[i];
         } else {
-            hpass(ty.s0, h0);
+            hpass(va[k], h0);
         }
-        hpass(ty.s1, h1);
-        prev_row = ty.s1;
-        const int b0 = ty.a0, b1 = ty.a1;
+        hpass(vb[k], h1);
+        const int b0 = ty[k].a0, b1 = ty[k].a1;
         uint32_t out = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {

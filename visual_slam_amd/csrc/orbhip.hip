@@ -29,6 +29,24 @@ const char* const kKernelNames[KC_COUNT] = {"k_level0", "k_resize", "k_fast", "k
 
 struct TimedSpan { int kc; hipEvent_t a, b; };
 
+// Device buffers of one pass. A handle owns two of them so that consecutive passes of a large
+// batch can run on two streams at once: the FAST / descriptor kernels are bound by the vector
+// ALUs, the pyramid kernels by memory and the quadtree by latency, so passes in different stages
+// fill each other's idle units.
+struct Workspace {
+    uint8_t* d_pyr = nullptr;
+    uint2* d_seg = nullptr;        // [frames][seg_per_frame]   FAST output segments
+    int* d_seg_count = nullptr;    // [frames][segc_per_frame]
+    uint2* d_keys = nullptr;       // [frames][keys_per_frame]  compact keys of the quadtree
+    int* d_key_count = nullptr;    // [frames][nlevels]
+    LevelKp* d_lvl_kp = nullptr;   // [frames][kp_per_frame]
+    int* d_lvl_cnt = nullptr;      // [frames][nlevels]
+    hipStream_t stream = nullptr;  // used when two passes are in flight
+    hipEvent_t done = nullptr;
+};
+const int kLanes = 4;
+const int kMinLaneFrames = 16;     // batches below twice this run as one pass on the caller's stream
+
 } // namespace
 
 struct orbhip_extractor {
@@ -46,16 +64,14 @@ struct orbhip_extractor {
     size_t pyr_bytes_per_frame = 0;
     PlanDev* d_plan = nullptr;
     RsTab* d_tabs = nullptr;
-    uint8_t* d_pyr = nullptr;
-    uint2* d_seg = nullptr;        // [frames][seg_per_frame]   FAST output segments
-    int* d_seg_count = nullptr;    // [frames][segc_per_frame]
-    uint2* d_keys = nullptr;       // [frames][keys_per_frame]  compact keys of the quadtree
-    int* d_key_count = nullptr;    // [frames][nlevels]
-    LevelKp* d_lvl_kp = nullptr;   // [frames][kp_per_frame]
-    int* d_lvl_cnt = nullptr;      // [frames][nlevels]
+    Workspace ws[kLanes];
+    int plan_lanes = 0;            // workspaces allocated for the current plan
+    int max_lanes = 2;             // ORBHIP_LANES=1 keeps every pass on the caller's stream
+    hipEvent_t ev_fork = nullptr;
     int* d_status = nullptr;       // bit0 candidate overflow, bit1 output capacity
     size_t qt_lds = 0;
     int last_pass_frames = 0;
+    int last_ws = 0;               // workspace of the last pass (pyramid / candidate read-back)
     // staging for the host entry points
     uint8_t* d_in = nullptr; size_t d_in_bytes = 0;
     float* d_out_kp = nullptr; uint8_t* d_out_desc = nullptr; int* d_out_cnt = nullptr;
@@ -85,9 +101,12 @@ void dfree(T*& p) {
 }
 
 void free_plan(orbhip_extractor* e) {
-    dfree(e->d_plan); dfree(e->d_tabs); dfree(e->d_pyr); dfree(e->d_seg); dfree(e->d_seg_count);
-    dfree(e->d_keys); dfree(e->d_key_count); dfree(e->d_lvl_kp); dfree(e->d_lvl_cnt);
-    e->plan_w = e->plan_h = e->plan_frames = 0;
+    dfree(e->d_plan); dfree(e->d_tabs);
+    for (Workspace& w : e->ws) {
+        dfree(w.d_pyr); dfree(w.d_seg); dfree(w.d_seg_count);
+        dfree(w.d_keys); dfree(w.d_key_count); dfree(w.d_lvl_kp); dfree(w.d_lvl_cnt);
+    }
+    e->plan_w = e->plan_h = e->plan_frames = e->plan_lanes = 0;
 }
 
 // Tap tables of cv::resize(8UC1, INTER_LINEAR): same construction as OpenCV's xofs/ialpha and
@@ -132,8 +151,9 @@ void blur_taps(int variant, int taps[4]) {   // cv::getGaussianKernel(7, 2, CV_3
     taps[0] = q[3]; taps[1] = q[2]; taps[2] = q[1]; taps[3] = q[0];
 }
 
-int ensure_plan(orbhip_extractor* e, int w, int h, int frames) {
-    if (e->plan_w == w && e->plan_h == h && e->plan_frames >= frames) return ORBHIP_OK;
+// Plan and workspaces for passes of up to `frames` frames, `lanes` of them in flight.
+int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
+    if (e->plan_w == w && e->plan_h == h && e->plan_frames >= frames && e->plan_lanes >= lanes) return ORBHIP_OK;
     if (w > 16384 || h > 16384) { e->err = "image larger than 16384 px"; return ORBHIP_ERR_GEOMETRY; }
     free_plan(e);
     PlanDev& P = e->plan;
@@ -228,17 +248,21 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames) {
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipMalloc(&e->d_plan, sizeof(PlanDev)));
     HIP_TRY(e, hipMalloc(&e->d_tabs, tabs.size() * sizeof(RsTab)));
-    HIP_TRY(e, hipMalloc(&e->d_pyr, pyr_off + 64));
-    HIP_TRY(e, hipMalloc(&e->d_seg, (size_t)P.seg_per_frame * frames * sizeof(uint2)));
-    HIP_TRY(e, hipMalloc(&e->d_seg_count, (size_t)P.segc_per_frame * frames * sizeof(int)));
-    HIP_TRY(e, hipMalloc(&e->d_keys, (size_t)P.keys_per_frame * frames * sizeof(uint2)));
-    HIP_TRY(e, hipMalloc(&e->d_key_count, (size_t)frames * nl * sizeof(int)));
-    HIP_TRY(e, hipMalloc(&e->d_lvl_kp, (size_t)frames * P.kp_per_frame * sizeof(LevelKp)));
-    HIP_TRY(e, hipMalloc(&e->d_lvl_cnt, (size_t)frames * nl * sizeof(int)));
+    for (int k = 0; k < lanes; k++) {
+        Workspace& W = e->ws[k];
+        HIP_TRY(e, hipMalloc(&W.d_pyr, pyr_off + 64));
+        HIP_TRY(e, hipMalloc(&W.d_seg, (size_t)P.seg_per_frame * frames * sizeof(uint2)));
+        HIP_TRY(e, hipMalloc(&W.d_seg_count, (size_t)P.segc_per_frame * frames * sizeof(int)));
+        HIP_TRY(e, hipMalloc(&W.d_keys, (size_t)P.keys_per_frame * frames * sizeof(uint2)));
+        HIP_TRY(e, hipMalloc(&W.d_key_count, (size_t)frames * nl * sizeof(int)));
+        HIP_TRY(e, hipMalloc(&W.d_lvl_kp, (size_t)frames * P.kp_per_frame * sizeof(LevelKp)));
+        HIP_TRY(e, hipMalloc(&W.d_lvl_cnt, (size_t)frames * nl * sizeof(int)));
+        HIP_TRY(e, hipMemsetAsync(W.d_lvl_kp, 0, (size_t)frames * P.kp_per_frame * sizeof(LevelKp), e->stream));
+    }
     HIP_TRY(e, hipMemcpyAsync(e->d_plan, &P, sizeof(PlanDev), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->d_tabs, tabs.data(), tabs.size() * sizeof(RsTab), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(e, hipMemsetAsync(e->d_lvl_kp, 0, (size_t)frames * P.kp_per_frame * sizeof(LevelKp), e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    e->plan_lanes = lanes;
     if (e->qt_lds > 64 * 1024)
         HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->qt_lds));
     e->plan_w = w; e->plan_h = h; e->plan_frames = frames;
@@ -263,7 +287,7 @@ struct SpanGuard {   // records a pair of events around a group of launches when
 };
 
 // One pass: `frames` frames starting at device pointer d_imgs; outputs written at frame index frame0.
-int run_pass(orbhip_extractor* e, hipStream_t s, const uint8_t* d_imgs, int frames, size_t row_stride,
+int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_imgs, int frames, size_t row_stride,
              size_t frame_stride, float* d_kp, uint8_t* d_desc, int* d_counts, int cap, int frame0) {
     const PlanDev& P = e->plan;
     const int nl = P.nlevels;
@@ -278,13 +302,13 @@ int run_pass(orbhip_extractor* e, hipStream_t s, const uint8_t* d_imgs, int fram
         const int i_lo = ORB_OX / 16, i_hi = (ORB_OX + g.w) / 16;
         if (aligned16 && i_hi > i_lo && g.h > ORB_EDGE && g.w > ORB_OX) {
             hipLaunchKernelGGL(k_level0_interior, dim3((i_hi - i_lo + 63) / 64, (g.rows + 3) / 4, frames), blk2, 0, s,
-                               d_imgs, row_stride, frame_stride, e->d_pyr, g, i_lo, i_hi);
+                               d_imgs, row_stride, frame_stride, W.d_pyr, g, i_lo, i_hi);
             const int nb = n16 - (i_hi - i_lo);
             hipLaunchKernelGGL(k_level0_edges, dim3((g.rows * nb + 255) / 256, frames), dim3(256), 0, s,
-                               d_imgs, row_stride, frame_stride, e->d_pyr, g, nb, i_lo, i_hi);
+                               d_imgs, row_stride, frame_stride, W.d_pyr, g, nb, i_lo, i_hi);
         } else {
             hipLaunchKernelGGL(k_level0_edges, dim3((g.rows * n16 + 255) / 256, frames), dim3(256), 0, s,
-                               d_imgs, row_stride, frame_stride, e->d_pyr, g, n16, n16, n16);
+                               d_imgs, row_stride, frame_stride, W.d_pyr, g, n16, n16, n16);
         }
     }
     for (int l = 1; l < nl; l++) {
@@ -292,30 +316,31 @@ int run_pass(orbhip_extractor* e, hipStream_t s, const uint8_t* d_imgs, int fram
         const LevelGeom& g = P.lv[l];
         const int ndw = (ORB_OX + g.w + ORB_EDGE + 3) / 4;
         hipLaunchKernelGGL(k_resize, dim3((ndw + 63) / 64, (g.rows + 4 * RS_RPT - 1) / (4 * RS_RPT), frames), blk2, 0, s,
-                           e->d_pyr, P.lv[l - 1], g, e->d_tabs, ndw);
+                           W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g, e->d_tabs, ndw);
     }
     for (int l = 0; l < nl; l++) {
         const LevelGeom& g = P.lv[l];
         if (g.ncols < 1) continue;
         SpanGuard t(e, s, KC_FAST);
         hipLaunchKernelGGL(k_fast, dim3(g.ntx, g.nty, frames), dim3(256), 0, s,
-                           e->d_pyr, g, P.min_th, P.seg_per_frame, P.segc_per_frame,
-                           e->d_seg, e->d_seg_count, e->d_status);
+                           W.d_pyr, g, P.min_th, P.seg_per_frame, P.segc_per_frame,
+                           W.d_seg, W.d_seg_count, e->d_status);
     }
     {
         SpanGuard t(e, s, KC_QUADTREE);
         hipLaunchKernelGGL(k_quadtree, dim3(nl, frames), dim3(QT_THREADS), e->qt_lds, s,
-                           e->d_plan, e->d_seg, e->d_seg_count, e->d_keys, e->d_key_count, e->d_lvl_kp, e->d_lvl_cnt,
+                           e->d_plan, W.d_seg, W.d_seg_count, W.d_keys, W.d_key_count, W.d_lvl_kp, W.d_lvl_cnt,
                            e->d_status);
     }
     {
         SpanGuard t(e, s, KC_DESCRIBE);
         const int maxkp = std::min(cap, P.kp_per_frame);
         hipLaunchKernelGGL(k_describe, dim3((maxkp + 3) / 4, frames), dim3(256), 0, s,
-                           e->d_plan, e->d_pyr, e->d_lvl_kp, e->d_lvl_cnt, d_kp, d_desc, d_counts, cap, frame0, e->d_status);
+                           e->d_plan, W.d_pyr, W.d_lvl_kp, W.d_lvl_cnt, d_kp, d_desc, d_counts, cap, frame0, e->d_status);
     }
     HIP_TRY(e, hipGetLastError());
     e->last_pass_frames = frames;
+    e->last_ws = (int)(&W - e->ws);
     return ORBHIP_OK;
 }
 
@@ -396,6 +421,12 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
         delete e;
         return ORBHIP_ERR_HIP;
     }
+    bool ok = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (Workspace& w : e->ws)
+        ok = ok && hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&w.done, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { orbhip_destroy(e); return ORBHIP_ERR_HIP; }
+    if (const char* v = std::getenv("ORBHIP_LANES")) e->max_lanes = std::min(kLanes, std::max(1, std::atoi(v)));
     *out = e;
     return ORBHIP_OK;
 }
@@ -409,6 +440,11 @@ int orbhip_destroy(orbhip_extractor* e) {
     free_plan(e);
     dfree(e->d_status); dfree(e->d_in); dfree(e->d_out_kp); dfree(e->d_out_desc); dfree(e->d_out_cnt);
     if (e->stream) (void)hipStreamDestroy(e->stream);
+    for (Workspace& w : e->ws) {
+        if (w.stream) (void)hipStreamDestroy(w.stream);
+        if (w.done) (void)hipEventDestroy(w.done);
+    }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     delete e;
     return ORBHIP_OK;
 }
@@ -425,19 +461,36 @@ int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int 
     // pyramid planes, FAST output segments, quadtree keys) under ~24 GB
     const double ws_per_frame = 20.0 * (double)width * (double)height;
     const int ws_limit = std::max(1, (int)(24e9 / ws_per_frame));
-    const int chunk = std::min(nframes, std::min(e->prm.max_batch, ws_limit));
-    if (e->plan_w != width || e->plan_h != height || e->plan_frames < chunk) {
+    const int budget = std::max(1, std::min(e->prm.max_batch, ws_limit));   // frames in flight
+    // Large batches run as passes of half the budget, alternating between two workspaces on two
+    // internal streams that fork from and join back into the caller's stream. Per-kernel timing
+    // needs the kernels one after the other and keeps to a single stream.
+    const int lanes = e->timing ? 1 : std::max(1, std::min(e->max_lanes, std::min(budget, nframes / kMinLaneFrames)));
+    const int chunk = lanes > 1 ? std::min((nframes + lanes - 1) / lanes, budget / lanes) : std::min(nframes, budget);
+    if (e->plan_w != width || e->plan_h != height || e->plan_frames < chunk || e->plan_lanes < lanes) {
         // a new plan frees the old workspaces: nothing may still be running on them
         HIP_TRY(e, hipDeviceSynchronize());
-        int rc = ensure_plan(e, width, height, chunk);
+        int rc = ensure_plan(e, width, height, std::max(chunk, e->plan_w == width && e->plan_h == height ? e->plan_frames : 0),
+                             std::max(lanes, e->plan_w == width && e->plan_h == height ? e->plan_lanes : 0));
         if (rc) return rc;
     }
-    for (int f0 = 0; f0 < nframes; f0 += chunk) {
+    if (lanes > 1) {
+        HIP_TRY(e, hipEventRecord(e->ev_fork, s));
+        for (int k = 0; k < lanes; k++) HIP_TRY(e, hipStreamWaitEvent(e->ws[k].stream, e->ev_fork, 0));
+    }
+    int pass = 0;
+    for (int f0 = 0; f0 < nframes; f0 += chunk, pass++) {
         const int n = std::min(chunk, nframes - f0);
-        int rc = run_pass(e, s, d_imgs + (size_t)f0 * frame_stride, n, row_stride, frame_stride,
+        Workspace& W = e->ws[pass % lanes];
+        int rc = run_pass(e, W, lanes > 1 ? W.stream : s, d_imgs + (size_t)f0 * frame_stride, n, row_stride, frame_stride,
                           reinterpret_cast<float*>(d_kp), d_desc, d_counts, cap, f0);
         if (rc) return rc;
     }
+    if (lanes > 1)
+        for (int k = 0; k < lanes; k++) {
+            HIP_TRY(e, hipEventRecord(e->ws[k].done, e->ws[k].stream));
+            HIP_TRY(e, hipStreamWaitEvent(s, e->ws[k].done, 0));
+        }
     return ORBHIP_OK;
 }
 
@@ -550,7 +603,7 @@ int orbhip_pyramid_copy(orbhip_extractor* e, int frame, int level, uint8_t* dst,
     if (dst_stride < (size_t)(g.w + 2 * b)) return ORBHIP_ERR_ARG;
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipDeviceSynchronize());
-    const uint8_t* src = e->d_pyr + g.pyr_off + (size_t)frame * g.plane_bytes + (size_t)(ORB_OY - b) * g.pitch + (ORB_OX - b);
+    const uint8_t* src = e->ws[e->last_ws].d_pyr + g.pyr_off + (size_t)frame * g.plane_bytes + (size_t)(ORB_OY - b) * g.pitch + (ORB_OX - b);
     HIP_TRY(e, hipMemcpy2D(dst, dst_stride, src, g.pitch, g.w + 2 * b, g.h + 2 * b, hipMemcpyDeviceToHost));
     return ORBHIP_OK;
 }
@@ -564,10 +617,11 @@ int orbhip_debug_candidates(orbhip_extractor* e, int frame, int level, orbhip_ca
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipDeviceSynchronize());
     int n = 0;
-    HIP_TRY(e, hipMemcpy(&n, e->d_key_count + frame * P.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    const Workspace& W = e->ws[e->last_ws];
+    HIP_TRY(e, hipMemcpy(&n, W.d_key_count + frame * P.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
     n = std::min(n, g.keys_cap);
     std::vector<uint2> raw((size_t)std::max(n, 1));
-    HIP_TRY(e, hipMemcpy(raw.data(), e->d_keys + (size_t)frame * P.keys_per_frame + g.keys_off, (size_t)n * sizeof(uint2), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(raw.data(), W.d_keys + (size_t)frame * P.keys_per_frame + g.keys_off, (size_t)n * sizeof(uint2), hipMemcpyDeviceToHost));
     struct Item { unsigned ord; orbhip_candidate c; };
     std::vector<Item> items;
     for (int i = 0; i < n; i++) {
