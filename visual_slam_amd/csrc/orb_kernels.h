@@ -26,18 +26,27 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // k_level0_interior: groups [g_lo, g_hi) of every row lie inside the image and the source is 16-byte
 // aligned. k_level0_edges: the remaining groups of a row (nb of them: those below skip_lo and from
 // skip_hi on), one thread per (row, group), reflecting byte path.
+#define L0_RPT 4                  // rows per thread of the interior copy
+
 __global__ __launch_bounds__(256) void k_level0_interior(const uint8_t* __restrict__ src, size_t row_stride,
                                                          size_t frame_stride, uint8_t* __restrict__ pyr,
                                                          LevelGeom g, int g_lo, int g_hi) {
     const int c16 = g_lo + blockIdx.x * 64 + threadIdx.x;
-    const int r = blockIdx.y * 4 + threadIdx.y;
+    const int r0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * L0_RPT;
     const int f = blockIdx.z;
-    if (c16 >= g_hi || r >= g.rows) return;
-    int sy = r - ORB_OY;
-    sy = sy < 0 ? -sy : (sy >= g.h ? 2 * (g.h - 1) - sy : sy);     // the border is narrower than the image
-    const uint8_t* S = src + (size_t)f * frame_stride + (size_t)sy * row_stride;
-    uint8_t* D = pyr + g.pyr_off + (size_t)f * g.plane_bytes + (size_t)r * g.pitch;
-    reinterpret_cast<uint4*>(D)[c16] = *reinterpret_cast<const uint4*>(S + (c16 * 16 - ORB_OX));
+    if (c16 >= g_hi || r0 >= g.rows) return;
+    const uint8_t* S = src + (size_t)f * frame_stride + (c16 * 16 - ORB_OX);
+    uint8_t* D = pyr + g.pyr_off + (size_t)f * g.plane_bytes;
+    uint4 v[L0_RPT];
+#pragma unroll
+    for (int k = 0; k < L0_RPT; k++) {                                  // all loads first: a wave is short
+        int sy = min(r0 + k, g.rows - 1) - ORB_OY;
+        sy = sy < 0 ? -sy : (sy >= g.h ? 2 * (g.h - 1) - sy : sy);     // the border is narrower than the image
+        v[k] = *reinterpret_cast<const uint4*>(S + (size_t)sy * row_stride);
+    }
+#pragma unroll
+    for (int k = 0; k < L0_RPT; k++)
+        if (r0 + k < g.rows) reinterpret_cast<uint4*>(D + (size_t)(r0 + k) * g.pitch)[c16] = v[k];
 }
 
 __global__ __launch_bounds__(256) void k_level0_edges(const uint8_t* __restrict__ src, size_t row_stride,
@@ -182,14 +191,7 @@ struct QtShared {
     unsigned long long* key64;  // [M] sort keys / best key per node
 };
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(v, o, 64);
-        if ((int)(threadIdx.x & 63) >= o) v += t;
-    }
-    return v;
-}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) { return wave_scan_incl(v); }   // DPP, no LDS traffic
 
 // In-place exclusive scan of a[0..n) by the whole workgroup; returns the total.
 __device__ uint32_t block_excl_scan(uint32_t* a, int n, uint32_t* s_tmp) {
@@ -217,6 +219,34 @@ __device__ __forceinline__ int qt_quadrant(uint32_t bx, uint32_t by, int x, int 
     const int x0 = bx & 0xFFFF, x1 = bx >> 16, y0 = by & 0xFFFF, y1 = by >> 16;
     const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);   // ceil(size/2)
     return (x < mx ? 0 : 1) | (y < my ? 0 : 2);
+}
+
+// Runs `body(e, k0)` over all keys of a thread (key k0 + u * QT_THREADS in e[u]; slots past the
+// end hold a dead key at the window origin), QT_KU keys per trip. The keys of the next trip are
+// requested before the body runs: the loops over keys are bound by memory latency.
+#define QT_KU 8
+template <typename F>
+__device__ __forceinline__ void qt_for_keys(const uint2* keys, int nkeys, int tid, F&& body) {
+    const uint2 dead = make_uint2(3u | (3u << 16), ORB_DEAD_LABEL << 10);
+    uint2 e[QT_KU];
+#pragma unroll
+    for (int u = 0; u < QT_KU; u++) {
+        const int k = tid + u * QT_THREADS;
+        e[u] = dead;
+        if (k < nkeys) e[u] = keys[k];
+    }
+    for (int k0 = tid; k0 < nkeys; k0 += QT_KU * QT_THREADS) {
+        uint2 nx[QT_KU];
+#pragma unroll
+        for (int u = 0; u < QT_KU; u++) {
+            const int k = k0 + (QT_KU + u) * QT_THREADS;
+            nx[u] = dead;
+            if (k < nkeys) nx[u] = keys[k];
+        }
+        body(e, k0);
+#pragma unroll
+        for (int u = 0; u < QT_KU; u++) e[u] = nx[u];
+    }
 }
 
 __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restrict__ plan,
@@ -248,7 +278,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         q.ordarr = p; p += M;
         q.cbase = p; p += M;
     }
-    uint32_t* cellbits = smem + 20 * M;            // one bit per FAST cell: it has a survivor >= iniTh
+    uint32_t* cellbits = smem + g.qt_words;        // one bit per FAST cell: it has a survivor >= iniTh
     uint2* keys = keys_all + (size_t)f * plan->keys_per_frame + g.keys_off;
     const int ini_th = plan->ini_th;
 
@@ -258,33 +288,46 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
     // it found nothing at iniThFAST)
     const int ncells = g.ncols * g.nrows;
     for (int i = tid; i < (ncells + 31) / 32; i += QT_THREADS) cellbits[i] = 0;
-    if (tid == 0) s_nkeys = 0;
-    __syncthreads();
+    const int nseg = g.ntx * g.nty * 4;
+    uint32_t* segbase = smem;                      // [nseg + 1], aliases the node arrays (not in use yet)
     {
-        const int nseg = g.ntx * g.nty * 4;
+        // step 1: segment sizes -> exclusive prefix sums = positions in `keys`
         const int* sc = seg_count + (size_t)f * plan->segc_per_frame + g.segc_off;
+        for (int sidx = tid; sidx < nseg; sidx += QT_THREADS) segbase[sidx] = (uint32_t)max(sc[sidx], 0);
+        __syncthreads();
+        const uint32_t total = block_excl_scan(segbase, nseg, s_tmp);
+        if (tid == 0) { segbase[nseg] = total; s_nkeys = (int)total; }
+        __syncthreads();
+        // step 2: 16 lanes copy one segment (most hold fewer than 16 entries), four segments of a
+        // lane group per trip so that their loads are in flight together
         const uint2* sbase = seg + (size_t)f * plan->seg_per_frame + g.seg_off;
-        for (int sidx = tid; sidx < nseg; sidx += QT_THREADS) {
-            const int n = sc[sidx];
-            if (n <= 0) continue;
-            const int base = atomicAdd(&s_nkeys, n);
-            const uint2* src = sbase + (size_t)sidx * FT_SEGCAP;
-            for (int i0 = 0; i0 < n; i0 += 4) {
-                uint2 e[4];
+        const int grp = tid >> 4, l16 = tid & 15;
+        auto place = [&](uint2 e, int pos) {
+            if (pos < g.keys_cap) keys[pos] = e;
+            if ((int)(e.y & 0xFF) >= ini_th) {
+                const int x = e.x & 0xFFFF, y = e.x >> 16;
+                const int c = (int)__umulhi((uint32_t)(y - 3), g.hcell_magic) * g.ncols +
+                              (int)__umulhi((uint32_t)(x - 3), g.wcell_magic);
+                atomicOr(&cellbits[c >> 5], 1u << (c & 31));
+            }
+        };
+        for (int s0 = grp; s0 < nseg; s0 += 4 * (QT_THREADS / 16)) {
+            int base[4], n[4];
+            uint2 e[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) e[u] = i0 + u < n ? src[i0 + u] : make_uint2(0u, 0u);
+            for (int u = 0; u < 4; u++) {
+                const int sidx = s0 + u * (QT_THREADS / 16);
+                base[u] = sidx < nseg ? (int)segbase[sidx] : 0;
+                n[u] = sidx < nseg ? (int)segbase[sidx + 1] - base[u] : 0;
+            }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int i = i0 + u;
-                    if (i >= n) break;
-                    if (base + i < g.keys_cap) keys[base + i] = e[u];
-                    if ((int)(e[u].y & 0xFF) >= ini_th) {
-                        const int x = e[u].x & 0xFFFF, y = e[u].x >> 16;
-                        const int c = (int)__umulhi((uint32_t)(y - 3), g.hcell_magic) * g.ncols +
-                                      (int)__umulhi((uint32_t)(x - 3), g.wcell_magic);
-                        atomicOr(&cellbits[c >> 5], 1u << (c & 31));
-                    }
-                }
+            for (int u = 0; u < 4; u++)
+                if (l16 < n[u]) e[u] = sbase[(size_t)(s0 + u * (QT_THREADS / 16)) * FT_SEGCAP + l16];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (l16 < n[u]) place(e[u], base[u] + l16);
+                for (int i = l16 + 16; i < n[u]; i += 16)
+                    place(sbase[(size_t)(s0 + u * (QT_THREADS / 16)) * FT_SEGCAP + i], base[u] + i);
             }
         }
     }
@@ -306,32 +349,30 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         q.cc[0][4 * i] = q.cc[0][4 * i + 1] = q.cc[0][4 * i + 2] = q.cc[0][4 * i + 3] = 0;
     }
     __syncthreads();
-    for (int k0 = tid; k0 < nkeys; k0 += 4 * QT_THREADS) {
-        uint2 e[4];
+    qt_for_keys(keys, nkeys, tid, [&](const uint2 (&e)[QT_KU], int k0) __attribute__((always_inline)) {
+        int x[QT_KU], y[QT_KU], s[QT_KU], cell[QT_KU], root[QT_KU];
+        uint32_t cb[QT_KU], b0[QT_KU], b1[QT_KU];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < QT_KU; u++) {
+            x[u] = e[u].x & 0xFFFF; y[u] = e[u].x >> 16; s[u] = e[u].y & 0xFF;
+            cell[u] = (int)__umulhi((uint32_t)(y[u] - 3), g.hcell_magic) * g.ncols + (int)__umulhi((uint32_t)(x[u] - 3), g.wcell_magic);
+            cb[u] = cellbits[cell[u] >> 5];
+            root[u] = min(max((int)__fdiv_rn((float)x[u], g.hx), 0), L - 1);
+            b0[u] = q.box[0][2 * root[u]]; b1[u] = q.box[0][2 * root[u] + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < QT_KU; u++) {
             const int k = k0 + u * QT_THREADS;
-            e[u] = k < nkeys ? keys[k] : make_uint2(0u, 0u);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (k0 + u * QT_THREADS >= nkeys) break;
-            const int x = e[u].x & 0xFFFF, y = e[u].x >> 16, s = e[u].y & 0xFF;
-            const int cx = (int)__umulhi((uint32_t)(x - 3), g.wcell_magic);
-            const int cy = (int)__umulhi((uint32_t)(y - 3), g.hcell_magic);
-            uint32_t lab = ORB_DEAD_LABEL;
-            uint32_t qd = 0;
-            const int cell = cy * g.ncols + cx;
-            if (s >= ini_th || ((cellbits[cell >> 5] >> (cell & 31)) & 1) == 0) {
-                int root = (int)__fdiv_rn((float)x, g.hx);
-                root = min(max(root, 0), L - 1);
-                qd = qt_quadrant(q.box[0][2 * root], q.box[0][2 * root + 1], x, y);
-                atomicAdd(&q.cc[0][4 * root + qd], 1u);
-                lab = root;
+            if (k >= nkeys) continue;
+            uint32_t lab = ORB_DEAD_LABEL, qd = 0;
+            if (s[u] >= ini_th || ((cb[u] >> (cell[u] & 31)) & 1) == 0) {
+                qd = qt_quadrant(b0[u], b1[u], x[u], y[u]);
+                atomicAdd(&q.cc[0][4 * root[u] + qd], 1u);
+                lab = root[u];
             }
-            keys[k0 + u * QT_THREADS].y = (uint32_t)s | (qd << 8) | (lab << 10);
+            keys[k].y = (uint32_t)s[u] | (qd << 8) | (lab << 10);
         }
-    }
+    });
     __syncthreads();
     for (int i = tid; i < L; i += QT_THREADS)
         q.cnt[0][i] = (q.cc[0][4 * i] + q.cc[0][4 * i + 1] + q.cc[0][4 * i + 2] + q.cc[0][4 * i + 3]) | QT_FRESH;
@@ -342,26 +383,34 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
     bool done = false;
     for (int round = 0; round < 64 && !done; round++) {
         const int nxt = cur ^ 1;
+        // double-buffered node arrays of this round as plain pointers (indexing the pointer table
+        // with a run-time index would put it into scratch memory)
+        uint32_t* const cc_cur = cur ? q.cc[1] : q.cc[0];
+        uint32_t* const cc_nxt = cur ? q.cc[0] : q.cc[1];
+        uint32_t* const box_cur = cur ? q.box[1] : q.box[0];
+        uint32_t* const box_nxt = cur ? q.box[0] : q.box[1];
+        uint32_t* const cnt_cur = cur ? q.cnt[1] : q.cnt[0];
+        uint32_t* const cnt_nxt = cur ? q.cnt[0] : q.cnt[1];
         // ---- A. which nodes split, and in which order
         if (tid < 4) s_red[tid] = 0;
         __syncthreads();
         uint32_t prev_size_l = 0;
-        for (int i = tid; i < L; i += QT_THREADS) prev_size_l += (q.cnt[cur][i] & ~QT_FRESH) > 0;
+        for (int i = tid; i < L; i += QT_THREADS) prev_size_l += (cnt_cur[i] & ~QT_FRESH) > 0;
         if (prev_size_l) atomicAdd(&s_red[0], prev_size_l);
         int nsplit;
         if (mode == 1) {
-            for (int i = tid; i < L; i += QT_THREADS) q.ordarr[i] = (q.cnt[cur][i] & ~QT_FRESH) > 1;
+            for (int i = tid; i < L; i += QT_THREADS) q.ordarr[i] = (cnt_cur[i] & ~QT_FRESH) > 1;
             __syncthreads();
             nsplit = (int)block_excl_scan(q.ordarr, L, s_tmp);
             for (int i = tid; i < L; i += QT_THREADS)
-                q.kord[i] = (q.cnt[cur][i] & ~QT_FRESH) > 1 ? (int)q.ordarr[i] : -1;
+                q.kord[i] = (cnt_cur[i] & ~QT_FRESH) > 1 ? (int)q.ordarr[i] : -1;
             __syncthreads();
         } else {
             // candidates: nodes created in the previous round that hold more than one key, largest
             // first; equal sizes: latest created first (= smaller list position)
             uint32_t ne_l = 0;
             for (int i = tid; i < L; i += QT_THREADS) {
-                const uint32_t c = q.cnt[cur][i];
+                const uint32_t c = cnt_cur[i];
                 const bool e = (c & QT_FRESH) && (c & ~QT_FRESH) > 1;
                 q.key64[i] = e ? (((unsigned long long)(c & ~QT_FRESH) << 32) | (0xFFFFFFFFu - (uint32_t)i)) : 0ull;
                 ne_l += e;
@@ -383,7 +432,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
             // growth of the list when the first r+1 candidates are split
             for (int r = tid; r < nE; r += QT_THREADS) {
                 const int i = q.ordarr[r];
-                const uint32_t* c = &q.cc[cur][4 * i];
+                const uint32_t* c = &cc_cur[4 * i];
                 q.cbase[r] = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0) - 1;
             }
             __syncthreads();
@@ -393,7 +442,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
             const int size0 = (int)s_red[0];
             for (int r = tid; r < nE; r += QT_THREADS) {
                 const int i = q.ordarr[r];
-                const uint32_t* c = &q.cc[cur][4 * i];
+                const uint32_t* c = &cc_cur[4 * i];
                 const int own = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0) - 1;
                 below_l += (size0 + (int)q.cbase[r] + own) < N;
             }
@@ -410,7 +459,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
             const int k = q.kord[i];
             if (k >= 0) {
                 q.ordarr[k] = i;
-                const uint32_t* c = &q.cc[cur][4 * i];
+                const uint32_t* c = &cc_cur[4 * i];
                 q.cbase[k] = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0);
             }
         }
@@ -418,43 +467,43 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         const int C = (int)block_excl_scan(q.cbase, nsplit, s_tmp);
         // ---- C. unsplit, non-empty nodes keep their relative order behind the children
         for (int i = tid; i < L; i += QT_THREADS)
-            q.surv[i] = (q.kord[i] < 0 && (q.cnt[cur][i] & ~QT_FRESH) > 0) ? 1u : 0u;
+            q.surv[i] = (q.kord[i] < 0 && (cnt_cur[i] & ~QT_FRESH) > 0) ? 1u : 0u;
         __syncthreads();
         const int S = (int)block_excl_scan(q.surv, L, s_tmp);
         const int Lnew = C + S;
         // ---- D. build the new list
         uint32_t expand_l = 0;
         for (int i = tid; i < L; i += QT_THREADS) {
-            const uint32_t c = q.cnt[cur][i] & ~QT_FRESH;
+            const uint32_t c = cnt_cur[i] & ~QT_FRESH;
             const int k = q.kord[i];
             if (k >= 0) {
-                const uint32_t bx = q.box[cur][2 * i], by = q.box[cur][2 * i + 1];
+                const uint32_t bx = box_cur[2 * i], by = box_cur[2 * i + 1];
                 const int x0 = bx & 0xFFFF, x1 = bx >> 16, y0 = by & 0xFFFF, y1 = by >> 16;
                 const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
                 int created = (int)q.cbase[k];
 #pragma unroll
                 for (int qd = 0; qd < 4; qd++) {
-                    const uint32_t n = q.cc[cur][4 * i + qd];
+                    const uint32_t n = cc_cur[4 * i + qd];
                     if (n == 0) continue;
                     const int pos = C - 1 - created++;
                     const int cx0 = (qd & 1) ? mx : x0, cx1 = (qd & 1) ? x1 : mx;
                     const int cy0 = (qd & 2) ? my : y0, cy1 = (qd & 2) ? y1 : my;
-                    q.box[nxt][2 * pos] = (uint32_t)cx0 | ((uint32_t)cx1 << 16);
-                    q.box[nxt][2 * pos + 1] = (uint32_t)cy0 | ((uint32_t)cy1 << 16);
-                    q.cnt[nxt][pos] = n | QT_FRESH;
-                    q.cc[cur][4 * i + qd] = (uint32_t)pos;
+                    box_nxt[2 * pos] = (uint32_t)cx0 | ((uint32_t)cx1 << 16);
+                    box_nxt[2 * pos + 1] = (uint32_t)cy0 | ((uint32_t)cy1 << 16);
+                    cnt_nxt[pos] = n | QT_FRESH;
+                    cc_cur[4 * i + qd] = (uint32_t)pos;
                     expand_l += n > 1;
                 }
             } else if (c > 0) {
                 const int pos = C + (int)q.surv[i];
-                q.box[nxt][2 * pos] = q.box[cur][2 * i];
-                q.box[nxt][2 * pos + 1] = q.box[cur][2 * i + 1];
-                q.cnt[nxt][pos] = c;
+                box_nxt[2 * pos] = box_cur[2 * i];
+                box_nxt[2 * pos + 1] = box_cur[2 * i + 1];
+                cnt_nxt[pos] = c;
                 q.surv[i] = (uint32_t)pos;
             }
         }
         if (expand_l) atomicAdd(&s_red[3], expand_l);
-        for (int i = tid; i < 4 * Lnew; i += QT_THREADS) q.cc[nxt][i] = 0;
+        for (int i = tid; i < 4 * Lnew; i += QT_THREADS) cc_nxt[i] = 0;
         __syncthreads();
         const int to_expand = (int)s_red[3];
         // ---- finish test (src/ORBextractor.cc:669-673, 734-735)
@@ -462,51 +511,64 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         else if (mode == 1 && Lnew + 3 * to_expand > N) mode = 2;
         // ---- E. keys follow their nodes
         if (!done) {
-            // four keys per thread and trip, loads first: the loop is bound by memory latency
-            for (int k0 = tid; k0 < nkeys; k0 += 4 * QT_THREADS) {
-                uint2 e[4];
+            qt_for_keys(keys, nkeys, tid, [&](const uint2 (&e)[QT_KU], int k0) __attribute__((always_inline)) {
+                uint32_t li[QT_KU], nl[QT_KU], bx[QT_KU], by[QT_KU];
+                int ko[QT_KU];
+                bool alive[QT_KU];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int k = k0 + u * QT_THREADS;
-                    e[u] = k < nkeys ? keys[k] : make_uint2(0u, ORB_DEAD_LABEL << 10);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < QT_KU; u++) {
                     const uint32_t lab = e[u].y >> 10;
-                    if (lab == ORB_DEAD_LABEL) continue;
-                    const uint32_t qd = (e[u].y >> 8) & 3;
-                    const uint32_t nl = q.kord[lab] >= 0 ? q.cc[cur][4 * lab + qd] : q.surv[lab];
-                    const int x = e[u].x & 0xFFFF, y = e[u].x >> 16;
-                    const uint32_t nq = qt_quadrant(q.box[nxt][2 * nl], q.box[nxt][2 * nl + 1], x, y);
-                    atomicAdd(&q.cc[nxt][4 * nl + nq], 1u);
-                    keys[k0 + u * QT_THREADS].y = (e[u].y & 0xFF) | (nq << 8) | (nl << 10);
+                    alive[u] = lab != ORB_DEAD_LABEL;
+                    li[u] = alive[u] ? lab : 0u;
+                    ko[u] = q.kord[li[u]];
                 }
-            }
+#pragma unroll
+                for (int u = 0; u < QT_KU; u++) {
+                    const uint32_t qd = (e[u].y >> 8) & 3;
+                    nl[u] = *(ko[u] >= 0 ? &cc_cur[4 * li[u] + qd] : &q.surv[li[u]]);
+                    if (!alive[u]) nl[u] = 0;
+                }
+#pragma unroll
+                for (int u = 0; u < QT_KU; u++) { bx[u] = box_nxt[2 * nl[u]]; by[u] = box_nxt[2 * nl[u] + 1]; }
+#pragma unroll
+                for (int u = 0; u < QT_KU; u++) {
+                    if (!alive[u]) continue;
+                    const uint32_t nq = qt_quadrant(bx[u], by[u], e[u].x & 0xFFFF, e[u].x >> 16);
+                    atomicAdd(&cc_nxt[4 * nl[u] + nq], 1u);
+                    keys[k0 + u * QT_THREADS].y = (e[u].y & 0xFF) | (nq << 8) | (nl[u] << 10);
+                }
+            });
         } else {
             // ---- best response per node, first in candidate order on ties (src/ORBextractor.cc:744-760)
             for (int i = tid; i < Lnew; i += QT_THREADS) q.key64[i] = 0ull;
             __syncthreads();
-            for (int k0 = tid; k0 < nkeys; k0 += 4 * QT_THREADS) {
-                uint2 e[4];
+            qt_for_keys(keys, nkeys, tid, [&](const uint2 (&e)[QT_KU], int) __attribute__((always_inline)) {
+                uint32_t li[QT_KU], nl[QT_KU];
+                int ko[QT_KU];
+                bool alive[QT_KU];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int k = k0 + u * QT_THREADS;
-                    e[u] = k < nkeys ? keys[k] : make_uint2(0u, ORB_DEAD_LABEL << 10);
+                for (int u = 0; u < QT_KU; u++) {
+                    const uint32_t lab = e[u].y >> 10;
+                    alive[u] = lab != ORB_DEAD_LABEL;
+                    li[u] = alive[u] ? lab : 0u;
+                    ko[u] = q.kord[li[u]];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t lab = e[u].y >> 10;
-                    if (lab == ORB_DEAD_LABEL) continue;
+                for (int u = 0; u < QT_KU; u++) {
                     const uint32_t qd = (e[u].y >> 8) & 3;
-                    const uint32_t nl = q.kord[lab] >= 0 ? q.cc[cur][4 * lab + qd] : q.surv[lab];
+                    nl[u] = *(ko[u] >= 0 ? &cc_cur[4 * li[u] + qd] : &q.surv[li[u]]);
+                }
+#pragma unroll
+                for (int u = 0; u < QT_KU; u++) {
+                    if (!alive[u]) continue;
                     const int x = e[u].x & 0xFFFF, y = e[u].x >> 16;
                     const int cx = (int)__umulhi((uint32_t)(x - 3), g.wcell_magic);
                     const int cy = (int)__umulhi((uint32_t)(y - 3), g.hcell_magic);
                     const uint32_t ord = (uint32_t)(((cy * g.ncols + cx) * g.hcell + (y - 3 - cy * g.hcell)) * g.wcell +
                                                     (x - 3 - cx * g.wcell));
-                    atomicMax(&q.key64[nl], ((unsigned long long)(e[u].y & 0xFF) << 32) | (0xFFFFFFFFu - ord));
+                    atomicMax(&q.key64[nl[u]], ((unsigned long long)(e[u].y & 0xFF) << 32) | (0xFFFFFFFFu - ord));
                 }
-            }
+            });
         }
         __syncthreads();
         L = Lnew;

@@ -213,7 +213,8 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
         g.seg_off = seg_off; seg_off += (size_t)g.ntx * g.nty * 4 * FT_SEGCAP;
         g.segc_off = segc_off; segc_off += g.ntx * g.nty * 4;
         g.keys_off = keys_off; keys_off += g.keys_cap;
-        max_qt_words = std::max(max_qt_words, (size_t)20 * g.node_cap + (size_t)(g.ncols * g.nrows + 31) / 32);
+        g.qt_words = std::max(20 * g.node_cap, g.ntx * g.nty * 4 + 1);
+        max_qt_words = std::max(max_qt_words, (size_t)g.qt_words + (size_t)(g.ncols * g.nrows + 31) / 32);
         g.quota = e->per_level[l];
         g.kp_off = kp_off; kp_off += g.node_cap;
         g.scale = e->sf[l];
@@ -301,7 +302,7 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
         // source is aligned; the groups that touch the border go through the reflecting byte path
         const int i_lo = ORB_OX / 16, i_hi = (ORB_OX + g.w) / 16;
         if (aligned16 && i_hi > i_lo && g.h > ORB_EDGE && g.w > ORB_OX) {
-            hipLaunchKernelGGL(k_level0_interior, dim3((i_hi - i_lo + 63) / 64, (g.rows + 3) / 4, frames), blk2, 0, s,
+            hipLaunchKernelGGL(k_level0_interior, dim3((i_hi - i_lo + 63) / 64, (g.rows + 4 * L0_RPT - 1) / (4 * L0_RPT), frames), blk2, 0, s,
                                d_imgs, row_stride, frame_stride, W.d_pyr, g, i_lo, i_hi);
             const int nb = n16 - (i_hi - i_lo);
             hipLaunchKernelGGL(k_level0_edges, dim3((g.rows * nb + 255) / 256, frames), dim3(256), 0, s,
