@@ -298,36 +298,40 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         const uint32_t total = block_excl_scan(segbase, nseg, s_tmp);
         if (tid == 0) { segbase[nseg] = total; s_nkeys = (int)total; }
         __syncthreads();
-        // step 2: 16 lanes copy one segment (most hold fewer than 16 entries), four segments of a
-        // lane group per trip so that their loads are in flight together
+        // step 2: one thread per key position p: binary search for its segment (the last one with
+        // segbase <= p; empty segments repeat a value), QT_KU positions per trip side by side so
+        // that the LDS reads of the searches and then the global loads are in flight together
         const uint2* sbase = seg + (size_t)f * plan->seg_per_frame + g.seg_off;
-        const int grp = tid >> 4, l16 = tid & 15;
-        auto place = [&](uint2 e, int pos) {
-            if (pos < g.keys_cap) keys[pos] = e;
-            if ((int)(e.y & 0xFF) >= ini_th) {
-                const int x = e.x & 0xFFFF, y = e.x >> 16;
-                const int c = (int)__umulhi((uint32_t)(y - 3), g.hcell_magic) * g.ncols +
-                              (int)__umulhi((uint32_t)(x - 3), g.wcell_magic);
-                atomicOr(&cellbits[c >> 5], 1u << (c & 31));
+        const int ncopy = min((int)total, g.keys_cap);
+        const int nsteps = nseg > 1 ? 32 - __clz(nseg - 1) : 0;
+        for (int p0 = tid; p0 < ncopy; p0 += QT_KU * QT_THREADS) {
+            int lo[QT_KU], hi[QT_KU];
+#pragma unroll
+            for (int u = 0; u < QT_KU; u++) { lo[u] = 0; hi[u] = nseg; }
+            for (int st = 0; st < nsteps; st++) {
+#pragma unroll
+                for (int u = 0; u < QT_KU; u++) {
+                    const int mid = (lo[u] + hi[u]) >> 1;
+                    if ((int)segbase[mid] <= min(p0 + u * QT_THREADS, ncopy - 1)) lo[u] = mid; else hi[u] = mid;
+                }
             }
-        };
-        for (int s0 = grp; s0 < nseg; s0 += 4 * (QT_THREADS / 16)) {
-            int base[4], n[4];
-            uint2 e[4];
+            uint2 e[QT_KU];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int sidx = s0 + u * (QT_THREADS / 16);
-                base[u] = sidx < nseg ? (int)segbase[sidx] : 0;
-                n[u] = sidx < nseg ? (int)segbase[sidx + 1] - base[u] : 0;
+            for (int u = 0; u < QT_KU; u++) {
+                const int p = min(p0 + u * QT_THREADS, ncopy - 1);
+                e[u] = sbase[(size_t)lo[u] * FT_SEGCAP + (p - (int)segbase[lo[u]])];
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (l16 < n[u]) e[u] = sbase[(size_t)(s0 + u * (QT_THREADS / 16)) * FT_SEGCAP + l16];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (l16 < n[u]) place(e[u], base[u] + l16);
-                for (int i = l16 + 16; i < n[u]; i += 16)
-                    place(sbase[(size_t)(s0 + u * (QT_THREADS / 16)) * FT_SEGCAP + i], base[u] + i);
+            for (int u = 0; u < QT_KU; u++) {
+                const int p = p0 + u * QT_THREADS;
+                if (p >= ncopy) continue;
+                keys[p] = e[u];
+                if ((int)(e[u].y & 0xFF) >= ini_th) {
+                    const int x = e[u].x & 0xFFFF, y = e[u].x >> 16;
+                    const int c = (int)__umulhi((uint32_t)(y - 3), g.hcell_magic) * g.ncols +
+                                  (int)__umulhi((uint32_t)(x - 3), g.wcell_magic);
+                    atomicOr(&cellbits[c >> 5], 1u << (c & 31));
+                }
             }
         }
     }
