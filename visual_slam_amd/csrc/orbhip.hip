@@ -66,7 +66,7 @@ struct orbhip_extractor {
     RsTab* d_tabs = nullptr;
     Workspace ws[kLanes];
     int plan_lanes = 0;            // workspaces allocated for the current plan
-    int max_lanes = 2;             // ORBHIP_LANES=1 keeps every pass on the caller's stream
+    int max_lanes = 1;             // ORBHIP_LANES=2..4: that many passes of a large batch in flight (a few % more throughput)
     hipEvent_t ev_fork = nullptr;
     int* d_status = nullptr;       // bit0 candidate overflow, bit1 output capacity
     size_t qt_lds = 0;
@@ -464,9 +464,9 @@ int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int 
     const int ws_limit = std::max(1, (int)(24e9 / ws_per_frame));
     const int budget = std::max(1, std::min(e->prm.max_batch, ws_limit));   // frames in flight
     // Large batches run as passes of half the budget, alternating between two workspaces on two
-    // internal streams that fork from and join back into the caller's stream. Per-kernel timing
-    // needs the kernels one after the other and keeps to a single stream.
-    const int lanes = e->timing ? 1 : std::max(1, std::min(e->max_lanes, std::min(budget, nframes / kMinLaneFrames)));
+    // internal streams that fork from and join back into the caller's stream. (Per-kernel timing
+    // then measures every kernel as it runs, next to the other pass's kernels.)
+    const int lanes = std::max(1, std::min(e->max_lanes, std::min(budget, nframes / kMinLaneFrames)));
     const int chunk = lanes > 1 ? std::min((nframes + lanes - 1) / lanes, budget / lanes) : std::min(nframes, budget);
     if (e->plan_w != width || e->plan_h != height || e->plan_frames < chunk || e->plan_lanes < lanes) {
         // a new plan frees the old workspaces: nothing may still be running on them
