@@ -98,43 +98,31 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
     return v;
 }
 
-// Every lane holds a bit set (bit b = row b/4 of the block, pixel b%4 of the lane's group). The
-// set bits of the wave are numbered lane by lane; those numbered base .. base+FT_QUEUE-1 are
-// written to the queue as  xl | (row0 + b/4) << 8.
+// Queue entries are raw codes  tag << 11 | lane << 5 | b  (b = index of a set bit in the lane's
+// word); they are decoded 64 at a time where they are consumed, which keeps the fill loop (one trip
+// per set bit of the fullest lane) short. The set bits of the wave are numbered lane by lane.
 // CHECKED: only entries whose slot lies in [lo, FT_QUEUE) are written (the caller makes several
 // passes); otherwise the caller guarantees that all of them fit.
 template <bool CHECKED>
-__device__ __forceinline__ void fast_fill_queue(uint32_t bits, int idx, int lo, int lane, int row0, uint16_t* queue) {
-    const uint32_t base0 = (uint32_t)(4 * lane) | ((uint32_t)row0 << 8);
+__device__ __forceinline__ void fast_fill_queue(uint32_t bits, int idx, int lo, uint32_t code0, uint16_t* queue) {
     while (bits) {
         const uint32_t b = (uint32_t)__ffs(bits) - 1;
         bits &= bits - 1;
-        if (!CHECKED || (idx >= lo && idx < FT_QUEUE)) queue[idx] = (uint16_t)(base0 + (b & 3) + ((b >> 2) << 8));
-        idx++;
-    }
-}
-
-// The sieve's verdict word: bit 8*i + 7 - j <-> row j of the step, pixel i of the lane's group.
-// Same numbering and queue format as fast_fill_queue.
-template <bool CHECKED>
-__device__ __forceinline__ void fast_fill_sieve(uint32_t bits, int idx, int lo, int lane, int row0, uint16_t* queue) {
-    const uint32_t base0 = (uint32_t)(4 * lane) | ((uint32_t)row0 << 8);
-    while (bits) {
-        const uint32_t b = (uint32_t)__ffs(bits) - 1;
-        bits &= bits - 1;
-        if (!CHECKED || (idx >= lo && idx < FT_QUEUE)) queue[idx] = (uint16_t)(base0 + (b >> 3) + ((~b & 7) << 8));
+        if (!CHECKED || (idx >= lo && idx < FT_QUEUE)) queue[idx] = (uint16_t)(code0 | b);
         idx++;
     }
 }
 
 // Scores `n` (<= 64) queued pixels, one per lane, from the LDS image tile into the tile map.
-// Queue entry: xl | map_row << 8; image tile row = map row + 3.
+// Queue entry: step << 11 | lane << 5 | b with b = 8 * pixel + 7 - row (the sieve's verdict word);
+// map row = m0 + FT_GROUP * step + row, image tile row = map row + 3.
 // A pixel that reaches min_th also sets its bit in `occ` (8 words per map row, bit = tile column).
-__device__ __forceinline__ void fast_score_queue(const uint16_t* queue, int n, int lane, const uint8_t* img,
+__device__ __forceinline__ void fast_score_queue(const uint16_t* queue, int n, int lane, int m0, const uint8_t* img,
                                                  int min_th, uint8_t* map, uint32_t* occ) {
     if (lane < n) {
-        const int e = queue[lane];
-        const int xl = e & 0xFF, row = e >> 8;
+        const uint32_t e = queue[lane];
+        const int xl = (int)((e >> 3) & 0xFC) + (int)((e >> 3) & 3);        // 4 * lane + pixel
+        const int row = m0 + FT_GROUP * (int)(e >> 11) + (int)(~e & 7);
         const uint8_t* c = img + (row + 3) * FT_P + xl;
         int p[16];
         p[0] = c[3 * FT_P];      p[1] = c[3 * FT_P + 1];   p[2] = c[2 * FT_P + 2];   p[3] = c[FT_P + 3];
@@ -270,9 +258,10 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
             const uint32_t incl = wave_scan_incl(cnt);
             const int total = (int)__shfl(incl, 63, 64);
             const int first = (int)(incl - cnt);
+            const uint32_t code0 = ((uint32_t)grp << 11) | ((uint32_t)lane << 5);
             auto drain = [&](int n) {                          // n entries queued: score the full batches
                 const int nfull = n & ~63;
-                for (int q = 0; q < nfull; q += 64) fast_score_queue(queue + q, 64, lane, s_img, min_th, s_map, s_occ);
+                for (int q = 0; q < nfull; q += 64) fast_score_queue(queue + q, 64, lane, m0, s_img, min_th, s_map, s_occ);
                 pending = n - nfull;
                 if (nfull && lane < pending) {
                     const uint16_t v = queue[nfull + lane];
@@ -280,19 +269,19 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
                 }
             };
             if (pending + total <= FT_QUEUE) {
-                fast_fill_sieve<false>(verdict, pending + first, 0, lane, mg, queue);
+                fast_fill_queue<false>(verdict, pending + first, 0, code0, queue);
                 drain(pending + total);
             } else {
                 for (int wb = 0; wb < total;) {
                     const int room = FT_QUEUE - pending;
-                    fast_fill_sieve<true>(verdict, first - wb + pending, pending, lane, mg, queue);
+                    fast_fill_queue<true>(verdict, first - wb + pending, pending, code0, queue);
                     drain(pending + min(room, total - wb));
                     wb += room;
                 }
             }
         }
     }
-    if (pending) fast_score_queue(queue, pending, lane, s_img, min_th, s_map, s_occ);
+    if (pending) fast_score_queue(queue, pending, lane, m0, s_img, min_th, s_map, s_occ);
     __syncthreads();                                           // all scores of the tile are in the map
 
     // ---- non-maximum suppression inside the cell and emission, map rows 1+8*wv .. 8+8*wv
@@ -315,15 +304,15 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
         const int total = (int)__shfl(incl, 63, 64);
         const int first = (int)(incl - cnt);
         for (int wb = 0; wb < total; wb += FT_QUEUE) {
-            if (total <= FT_QUEUE) fast_fill_queue<false>(bits, first, 0, lane, mh, queue);
-            else fast_fill_queue<true>(bits, first - wb, 0, lane, mh, queue);
+            if (total <= FT_QUEUE) fast_fill_queue<false>(bits, first, 0, (uint32_t)lane << 5, queue);
+            else fast_fill_queue<true>(bits, first - wb, 0, (uint32_t)lane << 5, queue);
             const int nw = min(FT_QUEUE, total - wb);
             for (int q = 0; q < nw; q += 64) {
                 bool keep = false;
                 int x = 0, y = 0, s = 0;
                 if (q + lane < nw) {
-                    const int e = queue[q + lane];
-                    const int xl = e & 0xFF, m = e >> 8;
+                    const uint32_t e = queue[q + lane];                   // lane << 5 | 4 * row + pixel
+                    const int xl = (int)((e >> 3) & 0xFC) + (int)(e & 3), m = mh + (int)((e >> 2) & 7);
                     const uint8_t* c = &s_map[m * FT_P + xl];
                     s = c[0];
                     x = xs - 4 + xl; y = y0 - 1 + m;
