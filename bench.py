@@ -72,6 +72,25 @@ def algorithmic_bytes(w, h, scale, levels, n_out):
     return parts, sum(parts.values())
 
 
+def compulsory_bytes(w, h, scale, levels, n_out):
+    """Stricter lower bound: input read + bordered pyramid write + outputs (no intermediate re-reads)."""
+    lv = level_sizes(w, h, scale, levels)
+    return w * h + sum((a + 38) * (b + 38) for a, b in lv) + 60 * n_out
+
+
+def device_copy_gbs(torch, device, nbytes=1 << 30, reps=5):
+    """Measured device-to-device copy bandwidth (read + write bytes per second) of this GPU."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (time.perf_counter() - t0) / 1e9
+
+
 def profiled_traffic(kernel, frames):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary
     (profiles/*_traffic.json, FETCH_SIZE/WRITE_SIZE passes), scaled to `frames` per launch."""
@@ -190,11 +209,15 @@ def main():
         passes = max(timing["k_quadtree"][1], 1)            # one quadtree launch per pass
         frames_per_launch = B * args.steps / passes
         traffic, traffic_src = profiled_traffic(kname, frames_per_launch)
+        copy_gbs = device_copy_gbs(torch, device)
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": int(k_bytes_per_launch), "avg_launch_ms": round(k_avg_s * 1e3, 4),
                     "whole_path_bytes_per_frame": int(total_bytes),
                     "whole_path_frac": round(fps / world * total_bytes / 1e9 / HBM_PEAK_GBS, 4),
+                    "compulsory_bytes_per_frame": int(compulsory_bytes(w, h, scale, levels, nfeat)),
+                    "device_copy_GBs": round(copy_gbs, 1),
+                    "whole_path_frac_of_copy": round(fps / world * total_bytes / 1e9 / copy_gbs, 4),
                     "frames_per_pass": int(frames_per_launch), "passes_in_flight": lanes,
                     "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in timing.items()}}
         # with several passes in flight (ORBHIP_LANES > 1) also time the same kernels one at a time (a

@@ -74,6 +74,8 @@ struct orbhip_extractor {
     int last_ws = 0;               // workspace of the last pass (pyramid / candidate read-back)
     // staging for the host entry points
     uint8_t* d_in = nullptr; size_t d_in_bytes = 0;
+    uint8_t* h_in = nullptr; size_t h_in_bytes = 0;      // pinned: rows are packed here, then one copy up
+    uint8_t* h_out = nullptr; size_t h_out_bytes = 0;    // pinned: counts, keypoints, descriptors in one copy down each
     float* d_out_kp = nullptr; uint8_t* d_out_desc = nullptr; int* d_out_cnt = nullptr;
     size_t d_out_frames = 0; int d_out_cap = 0;
     // timing
@@ -440,6 +442,8 @@ int orbhip_destroy(orbhip_extractor* e) {
     for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
     free_plan(e);
     dfree(e->d_status); dfree(e->d_in); dfree(e->d_out_kp); dfree(e->d_out_desc); dfree(e->d_out_cnt);
+    if (e->h_in) (void)hipHostFree(e->h_in);
+    if (e->h_out) (void)hipHostFree(e->h_out);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     for (Workspace& w : e->ws) {
         if (w.stream) (void)hipStreamDestroy(w.stream);
@@ -518,6 +522,12 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int nframes, 
         HIP_TRY(e, hipMalloc(&e->d_in, need));
         e->d_in_bytes = need;
     }
+    if (need > e->h_in_bytes) {
+        if (e->h_in) (void)hipHostFree(e->h_in);
+        e->h_in = nullptr; e->h_in_bytes = 0;
+        HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_in), need, hipHostMallocDefault));
+        e->h_in_bytes = need;
+    }
     if ((size_t)nframes > e->d_out_frames || cap != e->d_out_cap) {
         HIP_TRY(e, hipDeviceSynchronize());
         dfree(e->d_out_kp); dfree(e->d_out_desc); dfree(e->d_out_cnt);
@@ -526,24 +536,40 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int nframes, 
         HIP_TRY(e, hipMalloc(&e->d_out_cnt, (size_t)nframes * sizeof(int)));
         e->d_out_frames = nframes; e->d_out_cap = cap;
     }
-    for (int f = 0; f < nframes; f++)
-        HIP_TRY(e, hipMemcpy2DAsync(e->d_in + f * dev_frame, dev_row, imgs + f * frame_stride, row_stride, width, height,
-                                    hipMemcpyHostToDevice, e->stream));
+    const size_t kp_bytes = (size_t)nframes * cap * sizeof(orbhip_keypoint), desc_bytes = (size_t)nframes * cap * 32;
+    const size_t cnt_bytes = ((size_t)nframes * sizeof(int) + 15) & ~(size_t)15;
+    if (kp_bytes + desc_bytes + cnt_bytes > e->h_out_bytes) {
+        if (e->h_out) (void)hipHostFree(e->h_out);
+        e->h_out = nullptr; e->h_out_bytes = 0;
+        HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_out), kp_bytes + desc_bytes + cnt_bytes, hipHostMallocDefault));
+        e->h_out_bytes = kp_bytes + desc_bytes + cnt_bytes;
+    }
+    // pack the rows into the pinned buffer (a 2-D copy from pageable memory would go row by row)
+    for (int f = 0; f < nframes; f++) {
+        const uint8_t* src = imgs + (size_t)f * frame_stride;
+        uint8_t* dst = e->h_in + (size_t)f * dev_frame;
+        if (row_stride == dev_row) std::memcpy(dst, src, dev_frame);
+        else for (int y = 0; y < height; y++) std::memcpy(dst + (size_t)y * dev_row, src + (size_t)y * row_stride, (size_t)width);
+    }
+    HIP_TRY(e, hipMemcpyAsync(e->d_in, e->h_in, need, hipMemcpyHostToDevice, e->stream));
     int rc = orbhip_extract_batch_device(e, e->d_in, nframes, width, height, dev_row, dev_frame,
                                          reinterpret_cast<orbhip_keypoint*>(e->d_out_kp), e->d_out_desc, e->d_out_cnt, cap, nullptr);
     if (rc) return rc;
-    HIP_TRY(e, hipMemcpyAsync(counts, e->d_out_cnt, (size_t)nframes * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    uint8_t* h_cnt = e->h_out, *h_kp = e->h_out + cnt_bytes, *h_desc = h_kp + kp_bytes;
+    HIP_TRY(e, hipMemcpyAsync(h_cnt, e->d_out_cnt, (size_t)nframes * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(h_kp, e->d_out_kp, kp_bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(h_desc, e->d_out_desc, desc_bytes, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     collect_timing(e);
     rc = check_status(e);
     if (rc) return rc;
+    std::memcpy(counts, h_cnt, (size_t)nframes * sizeof(int));
     for (int f = 0; f < nframes; f++) {
-        const int n = counts[f];
+        const int n = std::min(counts[f], cap);
         if (n <= 0) continue;
-        HIP_TRY(e, hipMemcpyAsync(kp + (size_t)f * cap, e->d_out_kp + (size_t)f * cap * 7, (size_t)n * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipMemcpyAsync(desc + (size_t)f * cap * 32, e->d_out_desc + (size_t)f * cap * 32, (size_t)n * 32, hipMemcpyDeviceToHost, e->stream));
+        std::memcpy(kp + (size_t)f * cap, h_kp + (size_t)f * cap * sizeof(orbhip_keypoint), (size_t)n * sizeof(orbhip_keypoint));
+        std::memcpy(desc + (size_t)f * cap * 32, h_desc + (size_t)f * cap * 32, (size_t)n * 32);
     }
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
     return ORBHIP_OK;
 }
 
