@@ -126,6 +126,30 @@ int orbhip_debug_candidates(orbhip_extractor* e, int frame, int level, orbhip_ca
 int orbhip_enable_timing(orbhip_extractor* e, int on);
 int orbhip_get_timing(orbhip_extractor* e, const char** names, float* ms, int* launches, int cap);
 
+/* Frame::ComputeStereoMatches (src/Frame.cc:481-653): for every left keypoint the right-image
+ * column of its match (mvuRight) and its depth (mvDepth), -1 where there is none. `left` and
+ * `right` are the two extractor instances of a stereo rig (mpORBextractorLeft / Right,
+ * src/Frame.cc:114-117) after they have extracted the two images of the same `nframes` pairs in
+ * one pass each (same image size, same parameters, same device); their pyramids are read where
+ * the extraction left them in device memory (the reference reads mvImagePyramid of both,
+ * src/Frame.cc:488,578,590,595). d_kp_* / d_desc_* / d_cnt_* are the outputs of
+ * orbhip_extract_batch_device ([nframes][cap] records, counts per frame); mb is the baseline in
+ * metres and mbf the baseline times fx (src/Frame.cc:144,511-513). d_uright / d_depth are
+ * [nframes][cap] floats, d_nmatch[nframes] receives the matches kept per pair (may be NULL).
+ * Enqueued on `stream` (NULL = left's own stream), which must be the stream the two extractions
+ * were enqueued on or be ordered after them. */
+int orbhip_stereo_match_batch_device(orbhip_extractor* left, orbhip_extractor* right, int nframes,
+                                     const orbhip_keypoint* d_kp_l, const uint8_t* d_desc_l, const int* d_cnt_l,
+                                     const orbhip_keypoint* d_kp_r, const uint8_t* d_desc_r, const int* d_cnt_r,
+                                     int cap, float mb, float mbf, float* d_uright, float* d_depth, int* d_nmatch,
+                                     void* stream);
+/* The same for one pair with host arrays (the last orbhip_extract of each instance): kp/desc as
+ * returned by orbhip_extract, uright / depth receive n_l floats. Waits for the result. */
+int orbhip_stereo_match(orbhip_extractor* left, orbhip_extractor* right,
+                        const orbhip_keypoint* kp_l, const uint8_t* desc_l, int n_l,
+                        const orbhip_keypoint* kp_r, const uint8_t* desc_r, int n_r,
+                        float mb, float mbf, float* uright, float* depth, int* nmatch);
+
 const char* orbhip_strerror(int code);
 const char* orbhip_last_error(const orbhip_extractor* e);
 

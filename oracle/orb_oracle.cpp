@@ -760,4 +760,129 @@ double orbo_extract_batch_mt(int nfeatures, float scale_factor, int nlevels, int
     return dt;
 }
 
+/* Frame::ComputeStereoMatches (reference src/Frame.cc:481-653) on the keypoints, descriptors and
+ * pyramids of a left and a right extractor (mvImagePyramid of both, src/Frame.cc:488,578,590,595).
+ * Hamming distance: ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1611-1627); thresholds
+ * TH_HIGH = 100, TH_LOW = 50 (src/ORBmatcher.cc:38-39). uright / depth receive mvuRight / mvDepth
+ * (-1 = no match). Returns the number of matches that survive the median test.
+ * Where the reference would index out of bounds (a row band beyond the image, an empty match
+ * list before the median) this restatement skips instead. */
+int orbo_stereo_match(const orbo_extractor* L, const orbo_extractor* R,
+                      const orbo_keypoint* kl, const uint8_t* dl, int nl,
+                      const orbo_keypoint* kr, const uint8_t* dr, int nr,
+                      float mb, float mbf, float* uright, float* depth) {
+    if (!L || !R || L->pyr.empty() || R->pyr.empty()) return -1;
+    for (int i = 0; i < nl; i++) { uright[i] = -1.0f; depth[i] = -1.0f; }                 /* :483-484 */
+    const int thOrbDist = (100 + 50) / 2;                                                  /* :486 */
+    const int nRows = L->pyr[0].h;                                                         /* :488 */
+    std::vector<std::vector<size_t>> vRowIndices(nRows);
+    for (int iR = 0; iR < nr; iR++) {                                                      /* :498-508 */
+        const float kpY = kr[iR].y;
+        const float r = 2.0f * L->sf[kr[iR].octave];
+        const int maxr = (int)std::ceil(kpY + r);
+        const int minr = (int)std::floor(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++)
+            if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back((size_t)iR);
+    }
+    const float minZ = mb, minD = 0, maxD = mbf / minZ;                                    /* :511-513 */
+    std::vector<std::pair<int, int>> vDistIdx;
+    auto hamming = [](const uint8_t* a, const uint8_t* b) {
+        int dist = 0;
+        for (int i = 0; i < 8; i++) {
+            uint32_t x, y;
+            std::memcpy(&x, a + 4 * i, 4); std::memcpy(&y, b + 4 * i, 4);
+            dist += __builtin_popcount(x ^ y);
+        }
+        return dist;
+    };
+    for (int iL = 0; iL < nl; iL++) {                                                      /* :519-639 */
+        const orbo_keypoint& kpL = kl[iL];
+        const int levelL = kpL.octave;
+        const float vL = kpL.y, uL = kpL.x;
+        const size_t row = (size_t)vL;
+        if (row >= (size_t)nRows) continue;
+        const std::vector<size_t>& vCandidates = vRowIndices[row];
+        if (vCandidates.empty()) continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = 100;
+        size_t bestIdxR = 0;
+        for (size_t iC = 0; iC < vCandidates.size(); iC++) {                               /* :543-564 */
+            const size_t iR = vCandidates[iC];
+            const orbo_keypoint& kpR = kr[iR];
+            if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+            const float uR = kpR.x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = hamming(dl + (size_t)iL * 32, dr + iR * 32);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        if (bestDist < thOrbDist) {                                                        /* :567-638 */
+            const float uR0 = kr[bestIdxR].x;
+            const float scaleFactor = L->inv_sf[kpL.octave];
+            const float scaleduL = std::round(kpL.x * scaleFactor);
+            const float scaledvL = std::round(kpL.y * scaleFactor);
+            const float scaleduR0 = std::round(uR0 * scaleFactor);
+            const int w = 5;
+            const Plane& PL = L->pyr[kpL.octave];
+            const Plane& PR = R->pyr[kpL.octave];
+            const int yl0 = (int)(scaledvL - w), xl0 = (int)(scaleduL - w);
+            float IL[11][11];
+            for (int i = 0; i < 11; i++)
+                for (int j = 0; j < 11; j++) IL[i][j] = (float)PL.px()[(ptrdiff_t)(yl0 + i) * (ptrdiff_t)PL.step + xl0 + j];
+            const float cL = IL[w][w];
+            for (int i = 0; i < 11; i++) for (int j = 0; j < 11; j++) IL[i][j] = IL[i][j] - cL;
+            int bestDistS = 2147483647;
+            int bestincR = 0;
+            const int Lw = 5;
+            float vDists[2 * 5 + 1];
+            const float iniu = scaleduR0 + Lw - w;
+            const float endu = scaleduR0 + Lw + w + 1;
+            if (iniu < 0 || endu >= PR.w) continue;                                        /* :590-591 */
+            for (int incR = -Lw; incR <= +Lw; incR++) {                                    /* :593-607 */
+                const int xr0 = (int)(scaleduR0 + incR - w);
+                float IR[11][11];
+                for (int i = 0; i < 11; i++)
+                    for (int j = 0; j < 11; j++) IR[i][j] = (float)PR.px()[(ptrdiff_t)(yl0 + i) * (ptrdiff_t)PR.step + xr0 + j];
+                const float cR = IR[w][w];
+                double acc = 0;
+                for (int i = 0; i < 11; i++)
+                    for (int j = 0; j < 11; j++) acc += std::fabs((double)(IL[i][j] - (IR[i][j] - cR)));
+                const float dist = (float)acc;
+                if (dist < bestDistS) { bestDistS = (int)dist; bestincR = incR; }
+                vDists[Lw + incR] = dist;
+            }
+            if (bestincR == -Lw || bestincR == Lw) continue;                               /* :609-610 */
+            const float dist1 = vDists[Lw + bestincR - 1];
+            const float dist2 = vDists[Lw + bestincR];
+            const float dist3 = vDists[Lw + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));  /* :617 */
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = L->sf[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR); /* :623 */
+            float disparity = (uL - bestuR);
+            if (disparity >= minD && disparity < maxD) {                                   /* :627-637 */
+                if (disparity <= 0) {
+                    disparity = 0.01;
+                    bestuR = uL - 0.01;
+                }
+                depth[iL] = mbf / disparity;
+                uright[iL] = bestuR;
+                vDistIdx.push_back(std::pair<int, int>(bestDistS, iL));
+            }
+        }
+    }
+    if (vDistIdx.empty()) return 0;
+    std::sort(vDistIdx.begin(), vDistIdx.end());                                           /* :640-652 */
+    const float median = vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    int kept = (int)vDistIdx.size();
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+        if (vDistIdx[i].first < thDist) break;
+        uright[vDistIdx[i].second] = -1;
+        depth[vDistIdx[i].second] = -1;
+        kept--;
+    }
+    return kept;
+}
+
 } // extern "C"

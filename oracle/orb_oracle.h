@@ -96,6 +96,15 @@ double orbo_extract_batch_mt(int nfeatures, float scale_factor, int nlevels, int
                              int w, int h, size_t row_stride, size_t frame_stride, int nthreads,
                              int* counts);
 
+/* Frame::ComputeStereoMatches (reference src/Frame.cc:481-653) on the last extractions of a left and
+ * a right instance: kl/dl/nl and kr/dr/nr are their keypoints and descriptors, mb / mbf the stereo
+ * baseline (metres) and baseline times fx. uright[nl] / depth[nl] receive mvuRight / mvDepth
+ * (-1 = none). Returns the number of matches kept. */
+int orbo_stereo_match(const orbo_extractor* L, const orbo_extractor* R,
+                      const orbo_keypoint* kl, const uint8_t* dl, int nl,
+                      const orbo_keypoint* kr, const uint8_t* dr, int nr,
+                      float mb, float mbf, float* uright, float* depth);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,8 @@ def lib():
         L.orbo_extract_batch_mt.restype = C.c_double
         L.orbo_extract_batch_mt.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                             C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, i32p]
+        L.orbo_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -152,6 +154,20 @@ class OracleExtractor:
         out = np.zeros(max(n, 1), KP_DTYPE)
         lib().orbo_level_keypoints(self._h, level, _ptr(out), n)
         return out[:n]
+
+
+def stereo_match(left, right, kp_l, desc_l, kp_r, desc_r, mb, mbf):
+    """Frame::ComputeStereoMatches (reference src/Frame.cc:481-653) on the last extractions of two
+    OracleExtractor instances. Returns (mvuRight, mvDepth, matches kept)."""
+    kp_l = np.ascontiguousarray(kp_l, KP_DTYPE); kp_r = np.ascontiguousarray(kp_r, KP_DTYPE)
+    desc_l = np.ascontiguousarray(desc_l, np.uint8); desc_r = np.ascontiguousarray(desc_r, np.uint8)
+    uright = np.zeros(max(len(kp_l), 1), np.float32)
+    depth = np.zeros(max(len(kp_l), 1), np.float32)
+    n = lib().orbo_stereo_match(left._h, right._h, _ptr(kp_l), _ptr(desc_l), len(kp_l), _ptr(kp_r), _ptr(desc_r), len(kp_r),
+                                mb, mbf, _ptr(uright), _ptr(depth))
+    if n < 0:
+        raise RuntimeError("orbo_stereo_match failed: %d" % n)
+    return uright[:len(kp_l)], depth[:len(kp_l)], n
 
 
 def resize_linear_u8(src, dw, dh):

@@ -1,0 +1,78 @@
+"""GPU parity of the stereo matching step (reference src/Frame.cc:481-653) against the CPU oracle.
+
+Synthetic rectified pairs: the right image is the left image with its content moved left by a
+per-band disparity, so true matches exist at known disparities.
+"""
+import numpy as np
+import pytest
+
+from visual_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+PARAMS = (2000, 1.2, 8, 20, 7)
+FX, BF = 718.856, 386.1448          # KITTI 00-02 calibration (Examples/Stereo/KITTI00-02.yaml)
+
+
+def make_pair(kind, w, h, index, disparities=(3, 12, 40)):
+    left = synth.frame(kind, w, h, index)
+    right = np.empty_like(left)
+    bands = np.array_split(np.arange(h), len(disparities))
+    for rows, d in zip(bands, disparities):
+        right[rows[0]:rows[-1] + 1, :w - d] = left[rows[0]:rows[-1] + 1, d:]
+        right[rows[0]:rows[-1] + 1, w - d:] = left[rows[0]:rows[-1] + 1, w - d:]
+    return left, right
+
+
+def run_pair(kind, w, h, index, params=PARAMS):
+    from oracle import orb_oracle as O
+    from visual_slam_amd import orbhip
+    left, right = make_pair(kind, w, h, index)
+    oL, oR = O.OracleExtractor(*params), O.OracleExtractor(*params)
+    okl, odl = oL.extract(left)
+    okr, odr = oR.extract(right)
+    ou, od, on = O.stereo_match(oL, oR, okl, odl, okr, odr, BF / FX, BF)
+    gL, gR = orbhip.ORBextractor(*params), orbhip.ORBextractor(*params)
+    gkl, gdl = gL(left, fetch_pyramid=False)
+    gkr, gdr = gR(right, fetch_pyramid=False)
+    gu, gd, gn = orbhip.ComputeStereoMatches(gL, gR, gkl, gdl, gkr, gdr, BF / FX, BF)
+    return (okl, ou, od, on), (gkl, gu, gd, gn)
+
+
+@pytest.mark.parametrize("kind,w,h", [("blocks", 1241, 376), ("blocks", 752, 480), ("lowc", 640, 480), ("noise", 320, 240)])
+def test_stereo_matches_bit_exact(kind, w, h):
+    (okl, ou, od, on), (gkl, gu, gd, gn) = run_pair(kind, w, h, 0)
+    assert len(okl) == len(gkl)
+    assert np.array_equal(okl["x"], gkl["x"]) and np.array_equal(okl["y"], gkl["y"])
+    assert gn == on
+    # float results come from the same float32 operations in the same order: bit-exact
+    assert np.array_equal(ou.view(np.uint32), gu.view(np.uint32))
+    assert np.array_equal(od.view(np.uint32), gd.view(np.uint32))
+    if kind == "blocks":
+        assert on > 100                                  # the synthetic pair really has matches
+        m = gu >= 0
+        disp = gkl["x"][m] - gu[m]
+        assert np.all(disp >= 0) and np.all(disp < BF / (BF / FX))
+
+
+def test_stereo_no_right_keypoints():
+    from visual_slam_amd import orbhip
+    left = synth.batch("blocks", 640, 480, 1)[0]
+    right = np.full_like(left, 100)
+    gL, gR = orbhip.ORBextractor(1000, 1.2, 8, 20, 7), orbhip.ORBextractor(1000, 1.2, 8, 20, 7)
+    kl, dl = gL(left, fetch_pyramid=False)
+    kr, dr = gR(right, fetch_pyramid=False)
+    assert len(kr) == 0
+    u, d, n = orbhip.ComputeStereoMatches(gL, gR, kl, dl, kr, dr, BF / FX, BF)
+    assert n == 0 and np.all(u == -1) and np.all(d == -1)
+
+
+def test_stereo_rejects_mismatched_instances():
+    from visual_slam_amd import orbhip
+    a = synth.batch("blocks", 640, 480, 1)[0]
+    b = synth.batch("blocks", 320, 240, 1)[0]
+    gL, gR = orbhip.ORBextractor(500, 1.2, 8, 20, 7), orbhip.ORBextractor(500, 1.2, 8, 20, 7)
+    kl, dl = gL(a, fetch_pyramid=False)
+    kr, dr = gR(b, fetch_pyramid=False)
+    with pytest.raises(orbhip.OrbHipError):
+        orbhip.ComputeStereoMatches(gL, gR, kl, dl, kr, dr, BF / FX, BF)

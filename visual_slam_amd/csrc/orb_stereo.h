@@ -1,0 +1,177 @@
+// Stereo matching of the keypoints of a rectified pair, Frame::ComputeStereoMatches of the reference
+// (src/Frame.cc:481-653), on the keypoints / descriptors / pyramids that the two extractions left
+// in device memory.
+//
+//   k_stereo_match   one wave per left keypoint:
+//     - candidates are the right keypoints whose row band [floor(y - 2 s), ceil(y + 2 s)] contains
+//       the left keypoint's row, whose octave differs by at most one and whose x lies in
+//       [uL - maxD, uL] (src/Frame.cc:498-508, 548-553). The reference keeps per-row index lists;
+//       the winner is the smallest Hamming distance below TH_HIGH, first index on ties
+//       (src/Frame.cc:537-563), which is a minimum over (distance, index) and needs no lists:
+//       every lane tests a strided share of all right keypoints.
+//     - 11x11 SAD (both patches minus their centre pixel) at 11 horizontal offsets in the pyramid
+//       level of the left keypoint, parabola through the best three, disparity test
+//       (src/Frame.cc:566-637). 121 (row, offset) work items over the lanes, partial sums added in LDS.
+//   k_stereo_median  one workgroup per frame: median of the SAD values of the matches, matches at
+//       or above 1.5 * 1.4 * median are dropped (src/Frame.cc:640-652).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "orb_device.h"
+
+#define ST_TH_HIGH 100        // ORBmatcher::TH_HIGH (src/ORBmatcher.cc:38)
+#define ST_TH_LOW 50          // ORBmatcher::TH_LOW  (src/ORBmatcher.cc:39)
+
+struct StKp { float x, y, size, angle, response; int octave, class_id; };   // cv::KeyPoint record (28 bytes)
+
+__global__ __launch_bounds__(256) void k_stereo_match(const PlanDev* __restrict__ plan,
+                                                      const uint8_t* __restrict__ pyr_l, const uint8_t* __restrict__ pyr_r,
+                                                      const StKp* __restrict__ kp_l, const uint8_t* __restrict__ desc_l,
+                                                      const int* __restrict__ cnt_l,
+                                                      const StKp* __restrict__ kp_r, const uint8_t* __restrict__ desc_r,
+                                                      const int* __restrict__ cnt_r, int cap, float mb, float mbf,
+                                                      float* __restrict__ uright, float* __restrict__ depth,
+                                                      int* __restrict__ sad_out) {
+    __shared__ int s_dist[4][12];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int f = blockIdx.y;
+    const int iL = blockIdx.x * 4 + wv;
+    const int nl = min(cnt_l[f], cap), nr = min(cnt_r[f], cap);
+    if (iL >= nl) return;                                      // waves are independent: no workgroup barrier below
+    const size_t o = (size_t)f * cap;
+    const StKp kL = kp_l[o + iL];
+    const int levelL = kL.octave;
+    const float vL = kL.y, uL = kL.x;
+    float out_u = -1.0f, out_d = -1.0f;                        // src/Frame.cc:483-484
+    int out_sad = -1;
+    const float minD = 0.f, maxD = __fdiv_rn(mbf, mb);         // src/Frame.cc:511-513
+    const float minU = uL - maxD, maxU = uL - minD;
+    const int row = (int)vL;
+    // ---- best right keypoint by descriptor distance
+    uint32_t best = 0xFFFFFFFFu;                               // distance << 16 | index
+    if (!(maxU < 0)) {
+        const uint4* dLp = reinterpret_cast<const uint4*>(desc_l + (o + iL) * 32);
+        const uint4 dl0 = dLp[0], dl1 = dLp[1];
+        for (int iR = lane; iR < nr; iR += 64) {
+            const StKp* k = kp_r + o + iR;
+            const float kpY = k->y, uR = k->x;
+            const int octR = k->octave;
+            const float r = 2.0f * plan->lv[octR].scale;
+            const int maxr = (int)ceilf(kpY + r), minr = (int)floorf(kpY - r);
+            if (row < minr || row > maxr) continue;
+            if (octR < levelL - 1 || octR > levelL + 1) continue;
+            if (!(uR >= minU && uR <= maxU)) continue;
+            const uint4* dRp = reinterpret_cast<const uint4*>(desc_r + (o + iR) * 32);
+            const uint4 a = dRp[0], b = dRp[1];
+            const int dist = __popc(a.x ^ dl0.x) + __popc(a.y ^ dl0.y) + __popc(a.z ^ dl0.z) + __popc(a.w ^ dl0.w) +
+                             __popc(b.x ^ dl1.x) + __popc(b.y ^ dl1.y) + __popc(b.z ^ dl1.z) + __popc(b.w ^ dl1.w);
+            if (dist < ST_TH_HIGH) best = min(best, ((uint32_t)dist << 16) | (uint32_t)iR);
+        }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, s, 64));
+    const int bestDist = best == 0xFFFFFFFFu ? ST_TH_HIGH : (int)(best >> 16);
+    const int thOrbDist = (ST_TH_HIGH + ST_TH_LOW) / 2;        // src/Frame.cc:486
+    if (bestDist < thOrbDist) {
+        // ---- sub-pixel match by correlation (src/Frame.cc:566-637)
+        const int bestIdxR = (int)(best & 0xFFFF);
+        const float uR0 = kp_r[o + bestIdxR].x;
+        const LevelGeom& g = plan->lv[levelL];
+        const float scaleFactor = __fdiv_rn(1.0f, g.scale);    // mvInvScaleFactors[octave]
+        const float scaleduL = roundf(kL.x * scaleFactor);
+        const float scaledvL = roundf(kL.y * scaleFactor);
+        const float scaleduR0 = roundf(uR0 * scaleFactor);
+        const int w = 5, L = 5;
+        const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+        if (!(iniu < 0 || endu >= (float)g.w)) {
+            const uint8_t* PL = pyr_l + g.pyr_off + (size_t)f * g.plane_bytes + (size_t)ORB_OY * g.pitch + ORB_OX;
+            const uint8_t* PR = pyr_r + g.pyr_off + (size_t)f * g.plane_bytes + (size_t)ORB_OY * g.pitch + ORB_OX;
+            const int yl0 = (int)(scaledvL - w), xl0 = (int)(scaleduL - w), xr00 = (int)(scaleduR0 - L - w);
+            int* dist = s_dist[wv];
+            if (lane < 11) dist[lane] = 0;
+            const int cL = PL[(yl0 + w) * g.pitch + xl0 + w];
+            for (int t = lane; t < 121; t += 64) {
+                const int i = t / 11, k = t - i * 11;           // patch row, offset index (incR = k - 5)
+                const uint8_t* rl = PL + (yl0 + i) * g.pitch + xl0;
+                const uint8_t* rr = PR + (yl0 + i) * g.pitch + xr00 + k;
+                const int cR = PR[(yl0 + w) * g.pitch + xr00 + k + w];
+                int acc = 0;
+#pragma unroll
+                for (int j = 0; j < 11; j++) acc += abs(((int)rl[j] - cL) - ((int)rr[j] - cR));
+                atomicAdd(&dist[k], acc);
+            }
+            // LDS operations of one wave complete in order: the sums are final when read back
+            const int dk = lane < 11 ? dist[lane] : 0x7FFFFF;
+            uint32_t bk = ((uint32_t)dk << 8) | (uint32_t)lane; // smallest distance, first offset on ties
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) bk = min(bk, (uint32_t)__shfl_xor((int)bk, s, 64));
+            const int kbest = (int)(bk & 0xFF), bestincR = kbest - L;
+            if (!(bestincR == -L || bestincR == L)) {
+                const float dist1 = (float)dist[kbest - 1], dist2 = (float)dist[kbest], dist3 = (float)dist[kbest + 1];
+                const float deltaR = __fdiv_rn(dist1 - dist3, 2.0f * (dist1 + dist3 - 2.0f * dist2));
+                if (!(deltaR < -1 || deltaR > 1)) {
+                    float bestuR = g.scale * ((float)scaleduR0 + (float)bestincR + deltaR);
+                    float disparity = uL - bestuR;
+                    if (disparity >= minD && disparity < maxD) {
+                        if (disparity <= 0) {
+                            disparity = (float)0.01;
+                            bestuR = (float)((double)uL - 0.01);
+                        }
+                        out_d = __fdiv_rn(mbf, disparity);
+                        out_u = bestuR;
+                        out_sad = (int)(bk >> 8);
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        uright[o + iL] = out_u;
+        depth[o + iL] = out_d;
+        sad_out[o + iL] = out_sad;
+    }
+}
+
+// One workgroup per frame. nmatch[f] receives the number of matches kept.
+__global__ __launch_bounds__(256) void k_stereo_median(const int* __restrict__ cnt_l, int cap, const int* __restrict__ sad,
+                                                       float* __restrict__ uright, float* __restrict__ depth,
+                                                       int* __restrict__ nmatch) {
+    __shared__ int s_cnt;
+    const int tid = threadIdx.x, f = blockIdx.x;
+    const int nl = min(cnt_l[f], cap);
+    const size_t o = (size_t)f * cap;
+    auto count_le = [&](int v) -> int {                         // matches with SAD <= v (v = -1: none)
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        int c = 0;
+        for (int i = tid; i < nl; i += 256) { const int s = sad[o + i]; c += s >= 0 && s <= v; }
+        if (c) atomicAdd(&s_cnt, c);
+        __syncthreads();
+        const int r = s_cnt;
+        __syncthreads();
+        return r;
+    };
+    const int m = count_le(0x7FFFFFFF);
+    if (m == 0) { if (tid == 0) nmatch[f] = 0; return; }
+    // element m/2 of the sorted distances = smallest v with count(<= v) >= m/2 + 1
+    int lo = -1, hi = 121 * 510;                                // count_le(lo) < need <= count_le(hi)
+    const int need = m / 2 + 1;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (count_le(mid) >= need) hi = mid; else lo = mid;
+    }
+    const float median = (float)hi;
+    const float thDist = 1.5f * 1.4f * median;                  // src/Frame.cc:642
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    int kept = 0;
+    for (int i = tid; i < nl; i += 256) {
+        const int s = sad[o + i];
+        if (s < 0) continue;
+        if ((float)s < thDist) kept++;
+        else { uright[o + i] = -1.0f; depth[o + i] = -1.0f; }
+    }
+    if (kept) atomicAdd(&s_cnt, kept);
+    __syncthreads();
+    if (tid == 0) nmatch[f] = s_cnt;
+}

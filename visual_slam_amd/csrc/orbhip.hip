@@ -16,6 +16,7 @@
 #include "../../include/orbhip.h"
 #include "orb_device.h"
 #include "orb_kernels.h"
+#include "orb_stereo.h"
 
 namespace {
 
@@ -78,6 +79,9 @@ struct orbhip_extractor {
     uint8_t* h_out = nullptr; size_t h_out_bytes = 0;    // pinned: counts, keypoints, descriptors in one copy down each
     float* d_out_kp = nullptr; uint8_t* d_out_desc = nullptr; int* d_out_cnt = nullptr;
     size_t d_out_frames = 0; int d_out_cap = 0;
+    // stereo matching (owned by the left instance of a pair)
+    int* d_st_sad = nullptr; size_t d_st_sad_n = 0;      // [frames][cap] SAD of the match, -1 = none
+    uint8_t* d_st_tmp = nullptr; size_t d_st_tmp_bytes = 0;   // staging of the host-array entry point
     // timing
     bool timing = false;
     std::vector<TimedSpan> spans;
@@ -442,6 +446,7 @@ int orbhip_destroy(orbhip_extractor* e) {
     for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
     free_plan(e);
     dfree(e->d_status); dfree(e->d_in); dfree(e->d_out_kp); dfree(e->d_out_desc); dfree(e->d_out_cnt);
+    dfree(e->d_st_sad); dfree(e->d_st_tmp);
     if (e->h_in) (void)hipHostFree(e->h_in);
     if (e->h_out) (void)hipHostFree(e->h_out);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -523,7 +528,8 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int nframes, 
         e->d_in_bytes = need;
     }
     if (need > e->h_in_bytes) {
-        if (e->h_in) (void)hipHostFree(e->h_in);
+        dfree(e->d_st_sad); dfree(e->d_st_tmp);
+    if (e->h_in) (void)hipHostFree(e->h_in);
         e->h_in = nullptr; e->h_in_bytes = 0;
         HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_in), need, hipHostMallocDefault));
         e->h_in_bytes = need;
@@ -683,6 +689,95 @@ int orbhip_get_timing(orbhip_extractor* e, const char** names, float* ms, int* l
         if (launches) launches[i] = e->kc_launches[i];
     }
     return KC_COUNT;
+}
+
+int orbhip_stereo_match_batch_device(orbhip_extractor* left, orbhip_extractor* right, int nframes,
+                                     const orbhip_keypoint* d_kp_l, const uint8_t* d_desc_l, const int* d_cnt_l,
+                                     const orbhip_keypoint* d_kp_r, const uint8_t* d_desc_r, const int* d_cnt_r,
+                                     int cap, float mb, float mbf, float* d_uright, float* d_depth, int* d_nmatch,
+                                     void* stream) {
+    if (!left || !right || !d_kp_l || !d_desc_l || !d_cnt_l || !d_kp_r || !d_desc_r || !d_cnt_r || !d_uright || !d_depth ||
+        cap < 1 || cap > 65535 || nframes < 1 || !(mb > 0.f))
+        return ORBHIP_ERR_ARG;
+    orbhip_extractor* e = left;
+    if (!left->plan_w || !right->plan_w || nframes > left->last_pass_frames || nframes > right->last_pass_frames) {
+        e->err = "stereo matching needs a pass of at least nframes frames on both instances";
+        return ORBHIP_ERR_STATE;
+    }
+    if (left->device != right->device || left->plan_w != right->plan_w || left->plan_h != right->plan_h ||
+        left->prm.nlevels != right->prm.nlevels || left->prm.scale_factor != right->prm.scale_factor) {
+        e->err = "left and right instances differ in device, image size or pyramid parameters";
+        return ORBHIP_ERR_ARG;
+    }
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    const size_t need = (size_t)nframes * cap + (size_t)nframes;   // + a counter per frame when the caller wants none
+    if (need > e->d_st_sad_n) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        dfree(e->d_st_sad);
+        HIP_TRY(e, hipMalloc(&e->d_st_sad, need * sizeof(int)));
+        e->d_st_sad_n = need;
+    }
+    // the level geometry of the two plans is the same function of (size, parameters); plane
+    // offsets depend on the frames a plan was made for, so each side is addressed with its own plan
+    if (left->plan_frames != right->plan_frames) {
+        e->err = "left and right instances must be used with the same pass size";
+        return ORBHIP_ERR_ARG;
+    }
+    hipLaunchKernelGGL(k_stereo_match, dim3((cap + 3) / 4, nframes), dim3(256), 0, s,
+                       left->d_plan, left->ws[left->last_ws].d_pyr, right->ws[right->last_ws].d_pyr,
+                       reinterpret_cast<const StKp*>(d_kp_l), d_desc_l, d_cnt_l,
+                       reinterpret_cast<const StKp*>(d_kp_r), d_desc_r, d_cnt_r, cap, mb, mbf, d_uright, d_depth, e->d_st_sad);
+    int* nm = d_nmatch;
+    hipLaunchKernelGGL(k_stereo_median, dim3(nframes), dim3(256), 0, s, d_cnt_l, cap, e->d_st_sad, d_uright, d_depth,
+                       nm ? nm : e->d_st_sad + (size_t)nframes * cap);
+    HIP_TRY(e, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_stereo_match(orbhip_extractor* left, orbhip_extractor* right,
+                        const orbhip_keypoint* kp_l, const uint8_t* desc_l, int n_l,
+                        const orbhip_keypoint* kp_r, const uint8_t* desc_r, int n_r,
+                        float mb, float mbf, float* uright, float* depth, int* nmatch) {
+    if (!left || !right || n_l < 0 || n_r < 0 || !uright || !depth) return ORBHIP_ERR_ARG;
+    if (n_l == 0) { if (nmatch) *nmatch = 0; return ORBHIP_OK; }
+    if (!kp_l || !desc_l || (n_r > 0 && (!kp_r || !desc_r))) return ORBHIP_ERR_ARG;
+    orbhip_extractor* e = left;
+    HIP_TRY(e, hipSetDevice(e->device));
+    const int cap = std::max(std::max(n_l, n_r), 1);
+    const size_t kpb = (size_t)cap * sizeof(orbhip_keypoint), db = (size_t)cap * 32, fb = (size_t)cap * sizeof(float);
+    const size_t need = 2 * kpb + 2 * db + 2 * fb + 64;
+    if (need > e->d_st_tmp_bytes) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        dfree(e->d_st_tmp);
+        HIP_TRY(e, hipMalloc(&e->d_st_tmp, need));
+        e->d_st_tmp_bytes = need;
+    }
+    uint8_t* p = e->d_st_tmp;
+    int* d_cnt = reinterpret_cast<int*>(p); p += 64;            // [0] n_l, [1] n_r, [2] matches
+    orbhip_keypoint* d_kl = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
+    orbhip_keypoint* d_kr = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
+    uint8_t* d_dl = p; p += db;
+    uint8_t* d_dr = p; p += db;
+    float* d_u = reinterpret_cast<float*>(p); p += fb;
+    float* d_d = reinterpret_cast<float*>(p);
+    const int cnt[3] = {n_l, n_r, 0};
+    HIP_TRY(e, hipDeviceSynchronize());                        // both extractions (two streams) are complete
+    HIP_TRY(e, hipMemcpy(d_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_kl, kp_l, (size_t)n_l * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_dl, desc_l, (size_t)n_l * 32, hipMemcpyHostToDevice));
+    if (n_r > 0) {
+        HIP_TRY(e, hipMemcpy(d_kr, kp_r, (size_t)n_r * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(d_dr, desc_r, (size_t)n_r * 32, hipMemcpyHostToDevice));
+    }
+    int rc = orbhip_stereo_match_batch_device(left, right, 1, d_kl, d_dl, d_cnt, d_kr, d_dr, d_cnt + 1, cap, mb, mbf,
+                                              d_u, d_d, d_cnt + 2, nullptr);
+    if (rc) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(uright, d_u, (size_t)n_l * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(depth, d_d, (size_t)n_l * sizeof(float), hipMemcpyDeviceToHost));
+    if (nmatch) HIP_TRY(e, hipMemcpy(nmatch, d_cnt + 2, sizeof(int), hipMemcpyDeviceToHost));
+    return ORBHIP_OK;
 }
 
 const char* orbhip_strerror(int code) {

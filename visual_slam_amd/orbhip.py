@@ -30,7 +30,7 @@ EXPORTS = [
     "orbhip_get_scale_sigma_squares", "orbhip_get_inverse_scale_sigma_squares",
     "orbhip_get_features_per_level", "orbhip_get_umax", "orbhip_pyramid_info", "orbhip_pyramid_copy",
     "orbhip_debug_candidates", "orbhip_enable_timing", "orbhip_get_timing", "orbhip_strerror",
-    "orbhip_last_error",
+    "orbhip_last_error", "orbhip_stereo_match", "orbhip_stereo_match_batch_device",
 ]
 
 
@@ -83,12 +83,37 @@ def lib():
         L.orbhip_strerror.restype = C.c_char_p
         L.orbhip_last_error.argtypes = [vp]
         L.orbhip_last_error.restype = C.c_char_p
+        L.orbhip_stereo_match.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, ip]
+        L.orbhip_stereo_match_batch_device.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float,
+                                                       vp, vp, vp, vp]
         _lib = L
     return _lib
 
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def ComputeStereoMatches(left, right, kp_l, desc_l, kp_r, desc_r, mb, mbf):
+    """Frame::ComputeStereoMatches (reference src/Frame.cc:481-653) for the pair the two ORBextractor
+    instances extracted last. Returns (mvuRight, mvDepth, matches kept)."""
+    kp_l = np.ascontiguousarray(kp_l, KP_DTYPE); kp_r = np.ascontiguousarray(kp_r, KP_DTYPE)
+    desc_l = np.ascontiguousarray(desc_l, np.uint8); desc_r = np.ascontiguousarray(desc_r, np.uint8)
+    n_l, n_r = len(kp_l), len(kp_r)
+    uright = np.full(max(n_l, 1), -1.0, np.float32)
+    depth = np.full(max(n_l, 1), -1.0, np.float32)
+    nm = C.c_int(0)
+    left._check(lib().orbhip_stereo_match(left._h, right._h, _ptr(kp_l), _ptr(desc_l), n_l, _ptr(kp_r), _ptr(desc_r), n_r,
+                                          mb, mbf, _ptr(uright), _ptr(depth), C.byref(nm)))
+    return uright[:n_l], depth[:n_l], nm.value
+
+
+def stereo_match_batch_device(left, right, nframes, d_kp_l, d_desc_l, d_cnt_l, d_kp_r, d_desc_r, d_cnt_r, cap,
+                              mb, mbf, d_uright, d_depth, d_nmatch=None, stream=None):
+    """Raw-pointer batch call on the device-resident outputs of two extract_batch_device calls."""
+    left._check(lib().orbhip_stereo_match_batch_device(left._h, right._h, nframes, d_kp_l, d_desc_l, d_cnt_l,
+                                                       d_kp_r, d_desc_r, d_cnt_r, cap, mb, mbf, d_uright, d_depth,
+                                                       d_nmatch, stream))
 
 
 class ORBextractor:
