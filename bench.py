@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--workload", default="C4_1080p_2000f", choices=sorted(WORKLOADS))
     ap.add_argument("--kind", default="blocks", choices=["blocks", "noise", "lowc"])
     ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--stereo", action="store_true", help="step = left + right extraction + stereo matching of every pair; value = pairs/s")
     ap.add_argument("--host-fed", action="store_true", help="also time the PCIe-inclusive host-buffer entry point")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for the barrier / max-time reduction")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses GPU 0 (use with --backend gloo)")
@@ -164,11 +165,27 @@ def main():
     d_kp = torch.empty((B, cap, 7), dtype=torch.float32, device=device)
     d_desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=device)
     d_cnt = torch.zeros((B,), dtype=torch.int32, device=device)
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream(device)   # one explicit stream for every library call of this rank
+
+    if args.stereo:
+        # right image of every pair: the left image moved 12 px to the left (KITTI 00-02 calibration)
+        exr = orbhip.ORBextractor(nfeat, scale, levels, ini_th, min_th, device=local_rank, max_batch=args.max_batch)
+        frames_r = torch.roll(frames, shifts=-12, dims=2).contiguous()
+        r_kp, r_desc, r_cnt = torch.empty_like(d_kp), torch.empty_like(d_desc), torch.zeros_like(d_cnt)
+        d_ur = torch.empty((B, cap), dtype=torch.float32, device=device)
+        d_dep = torch.empty((B, cap), dtype=torch.float32, device=device)
+        d_nm = torch.zeros((B,), dtype=torch.int32, device=device)
+        fx, bf = 718.856, 386.1448
 
     def step():
         ex.extract_batch_device(frames.data_ptr(), B, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(),
                                 d_cnt.data_ptr(), cap, stream.cuda_stream)
+        if args.stereo:
+            exr.extract_batch_device(frames_r.data_ptr(), B, w, h, w, w * h, r_kp.data_ptr(), r_desc.data_ptr(),
+                                     r_cnt.data_ptr(), cap, stream.cuda_stream)
+            orbhip.stereo_match_batch_device(ex, exr, B, d_kp.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(),
+                                             r_kp.data_ptr(), r_desc.data_ptr(), r_cnt.data_ptr(), cap, bf / fx, bf,
+                                             d_ur.data_ptr(), d_dep.data_ptr(), d_nm.data_ptr(), stream.cuda_stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -176,12 +193,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.synchronize()             # inputs were produced on torch's default stream
     for _ in range(args.warmup):
         step()
     barrier()
     # per-kernel device time of the timed steps themselves: HIP events recorded inside libORBhip
     # on the streams the kernels run on (two event records per launch, no host synchronisation)
     ex.enable_timing(True)
+    if args.stereo:
+        exr.enable_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -190,6 +210,11 @@ def main():
     ex.synchronize()   # raises on a deferred capacity error
     timing = ex.timing()
     ex.enable_timing(False)
+    if args.stereo:
+        exr.synchronize()
+        tr = exr.timing()
+        exr.enable_timing(False)
+        timing = {k: (timing[k][0] + tr[k][0], timing[k][1] + tr[k][1]) for k in timing}
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -200,13 +225,20 @@ def main():
         counts = d_cnt.cpu().numpy()
         n_out = float(counts.mean())
         parts, total_bytes = algorithmic_bytes(w, h, scale, levels, nfeat)
+        if args.stereo:
+            # per pair: both extractions + keypoint/descriptor records of both sides read, two floats per left keypoint written
+            parts = {k: 2 * v for k, v in parts.items()}
+            parts["k_stereo"] = 2 * 60 * nfeat + 8 * nfeat
+            total_bytes = sum(parts.values())
+        else:
+            parts["k_stereo"] = 0
         kname = max(timing, key=lambda k: timing[k][0])
         k_ms, k_launches = timing[kname]
         k_bytes_per_launch = parts[kname] * B * args.steps / max(k_launches, 1)
         k_avg_s = k_ms * 1e-3 / max(k_launches, 1)
         achieved = k_bytes_per_launch / k_avg_s / 1e9
         lanes = max(1, min(int(os.environ.get("ORBHIP_LANES", "1")), 4))
-        passes = max(timing["k_quadtree"][1], 1)            # one quadtree launch per pass
+        passes = max(timing["k_quadtree"][1] // (2 if args.stereo else 1), 1)   # one quadtree launch per pass and side
         frames_per_launch = B * args.steps / passes
         traffic, traffic_src = profiled_traffic(kname, frames_per_launch)
         copy_gbs = device_copy_gbs(torch, device)
@@ -264,14 +296,16 @@ def main():
             ex.extract_batch(host)
             extra["host_fed_frames_per_s"] = round(len(host) / (time.perf_counter() - t1), 1)
         line = {
-            "metric": "ORB extract frames/s (1080p, 2k feats)" if args.workload == "C4_1080p_2000f" else "ORB extract frames/s",
-            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": ("ORB extract + stereo match pairs/s" if args.stereo else
+                       "ORB extract frames/s (1080p, 2k feats)" if args.workload == "C4_1080p_2000f" else "ORB extract frames/s"),
+            "value": round(fps, 1), "unit": "pairs/s" if args.stereo else "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": args.workload, "image": [w, h], "nfeatures": nfeat, "levels": levels, "scale": scale,
                        "fast_th": [ini_th, min_th], "frames_per_gpu_per_step": B, "distribution": args.kind,
                        "inputs": "device-resident", "pyramid_copied_back": False, "blur_variant": "legacy",
-                       "mean_keypoints_per_frame": round(n_out, 1), "sharding": "frames, no collective"},
+                       "mean_keypoints_per_frame": round(n_out, 1), "sharding": "frames, no collective",
+                       **({"stereo": True, "mean_matches_per_pair": round(float(d_nm.float().mean().item()), 1)} if args.stereo else {})},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extra)

@@ -2,6 +2,7 @@
 // (src/Frame.cc:481-653), on the keypoints / descriptors / pyramids that the two extractions left
 // in device memory.
 //
+//   k_stereo_prep    one thread per right keypoint: its row band, octave and x as one 16-byte record
 //   k_stereo_match   one wave per left keypoint:
 //     - candidates are the right keypoints whose row band [floor(y - 2 s), ceil(y + 2 s)] contains
 //       the left keypoint's row, whose octave differs by at most one and whose x lies in
@@ -20,10 +21,51 @@
 
 #define ST_TH_HIGH 100        // ORBmatcher::TH_HIGH (src/ORBmatcher.cc:38)
 #define ST_TH_LOW 50          // ORBmatcher::TH_LOW  (src/ORBmatcher.cc:39)
+#define ST_CAND 256           // candidate list of one left keypoint in LDS
 
 struct StKp { float x, y, size, angle, response; int octave, class_id; };   // cv::KeyPoint record (28 bytes)
 
-__global__ __launch_bounds__(256) void k_stereo_match(const PlanDev* __restrict__ plan,
+// One workgroup per frame: the right keypoints as 16-byte records {minr, maxr, octave | index << 8,
+// bits of x} (row band as in src/Frame.cc:498-508), counting-sorted into bins of ST_BIN_ROWS rows
+// by minr. binstart[f][b] .. binstart[f][b + 1] is the record range of bin b. A left keypoint in
+// row v can only match records with minr in [v - band, v], i.e. a few consecutive bins.
+#define ST_BIN_SHIFT 4
+#define ST_BIN_ROWS (1 << ST_BIN_SHIFT)
+#define ST_MAX_BINS 1040          // 16384 rows / 16 + slack
+__global__ __launch_bounds__(256) void k_stereo_prep(const PlanDev* __restrict__ plan, const StKp* __restrict__ kp_r,
+                                                     const int* __restrict__ cnt_r, int cap, int nbins,
+                                                     int4* __restrict__ rinfo, int* __restrict__ binstart) {
+    __shared__ uint32_t s_hist[ST_MAX_BINS + 1];
+    __shared__ uint32_t s_tmp[4];
+    const int tid = threadIdx.x, f = blockIdx.x;
+    const int nr = min(cnt_r[f], cap);
+    const StKp* K = kp_r + (size_t)f * cap;
+    for (int b = tid; b <= nbins; b += 256) s_hist[b] = 0;
+    __syncthreads();
+    auto record = [&](int i, int& bin) -> int4 {
+        const StKp k = K[i];
+        const float r = 2.0f * plan->lv[k.octave].scale;
+        const int minr = (int)floorf(k.y - r), maxr = (int)ceilf(k.y + r);
+        bin = min(max(minr >> ST_BIN_SHIFT, 0), nbins - 1);
+        return make_int4(minr, maxr, k.octave | (i << 8), __float_as_int(k.x));
+    };
+    for (int i = tid; i < nr; i += 256) { int bin; record(i, bin); atomicAdd(&s_hist[bin], 1u); }
+    __syncthreads();
+    const uint32_t total = block_excl_scan(s_hist, nbins, s_tmp);
+    if (tid == 0) s_hist[nbins] = total;
+    __syncthreads();
+    int* bs = binstart + (size_t)f * (nbins + 1);
+    for (int b = tid; b <= nbins; b += 256) bs[b] = (int)s_hist[b];
+    __syncthreads();
+    for (int i = tid; i < nr; i += 256) {
+        int bin;
+        const int4 rec = record(i, bin);
+        rinfo[(size_t)f * cap + atomicAdd(&s_hist[bin], 1u)] = rec;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_stereo_match(const PlanDev* __restrict__ plan, const int4* __restrict__ rinfo,
+                                                      const int* __restrict__ binstart, int nbins, int band,
                                                       const uint8_t* __restrict__ pyr_l, const uint8_t* __restrict__ pyr_r,
                                                       const StKp* __restrict__ kp_l, const uint8_t* __restrict__ desc_l,
                                                       const int* __restrict__ cnt_l,
@@ -32,6 +74,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const PlanDev* __restrict_
                                                       float* __restrict__ uright, float* __restrict__ depth,
                                                       int* __restrict__ sad_out) {
     __shared__ int s_dist[4][12];
+    __shared__ uint16_t s_cand[4][ST_CAND];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int f = blockIdx.y;
@@ -52,21 +95,46 @@ __global__ __launch_bounds__(256) void k_stereo_match(const PlanDev* __restrict_
     if (!(maxU < 0)) {
         const uint4* dLp = reinterpret_cast<const uint4*>(desc_l + (o + iL) * 32);
         const uint4 dl0 = dLp[0], dl1 = dLp[1];
-        for (int iR = lane; iR < nr; iR += 64) {
-            const StKp* k = kp_r + o + iR;
-            const float kpY = k->y, uR = k->x;
-            const int octR = k->octave;
-            const float r = 2.0f * plan->lv[octR].scale;
-            const int maxr = (int)ceilf(kpY + r), minr = (int)floorf(kpY - r);
-            if (row < minr || row > maxr) continue;
-            if (octR < levelL - 1 || octR > levelL + 1) continue;
-            if (!(uR >= minU && uR <= maxU)) continue;
+        auto hamming = [&](int iR) {
             const uint4* dRp = reinterpret_cast<const uint4*>(desc_r + (o + iR) * 32);
             const uint4 a = dRp[0], b = dRp[1];
             const int dist = __popc(a.x ^ dl0.x) + __popc(a.y ^ dl0.y) + __popc(a.z ^ dl0.z) + __popc(a.w ^ dl0.w) +
                              __popc(b.x ^ dl1.x) + __popc(b.y ^ dl1.y) + __popc(b.z ^ dl1.z) + __popc(b.w ^ dl1.w);
             if (dist < ST_TH_HIGH) best = min(best, ((uint32_t)dist << 16) | (uint32_t)iR);
+        };
+        // Scan of the bins that can hold a candidate: 4 records per lane and trip, loads first. The
+        // indices that pass the geometric tests are compacted into a list in LDS so that their
+        // descriptors can then be fetched 64 at a time; what does not fit is handled on the spot.
+        uint16_t* cand = s_cand[wv];
+        int ncand = 0;
+        const int* bs = binstart + (size_t)f * (nbins + 1);
+        const int r_lo = bs[min(max((row - band) >> ST_BIN_SHIFT, 0), nbins - 1)];
+        const int r_hi = bs[min(max(row >> ST_BIN_SHIFT, 0), nbins - 1) + 1];
+        for (int base = r_lo; base < r_hi; base += 4 * 64) {     // wave-uniform trip count: ncand stays uniform
+            int4 ri[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int p = base + lane + 64 * u;
+                ri[u] = make_int4(1, 0, 0, 0);                 // empty row band: never a candidate
+                if (p < r_hi) ri[u] = rinfo[o + p];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int iR = ri[u].z >> 8, octR = ri[u].z & 0xFF;
+                const float uR = __int_as_float(ri[u].w);
+                const bool ok = row >= ri[u].x && row <= ri[u].y && octR >= levelL - 1 && octR <= levelL + 1 &&
+                                uR >= minU && uR <= maxU;
+                const unsigned long long m = __ballot(ok);
+                if (ok) {
+                    const int pos = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                    if (pos < ST_CAND) cand[pos] = (uint16_t)iR; else hamming(iR);
+                }
+                ncand += __popcll(m);
+            }
         }
+        ncand = min(ncand, ST_CAND);
+        for (int c0 = 0; c0 < ncand; c0 += 64)
+            if (c0 + lane < ncand) hamming(cand[c0 + lane]);
     }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, s, 64));

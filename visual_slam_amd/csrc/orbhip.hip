@@ -25,8 +25,8 @@ inline int cv_floor(double v) { int i = (int)v; return i - (i > v); }
 inline int cv_ceil(double v) { int i = (int)v; return i + (i < v); }
 inline short sat_short(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
 
-enum KernelClass { KC_LEVEL0 = 0, KC_RESIZE, KC_FAST, KC_QUADTREE, KC_DESCRIBE, KC_COUNT };
-const char* const kKernelNames[KC_COUNT] = {"k_level0", "k_resize", "k_fast", "k_quadtree", "k_describe"};
+enum KernelClass { KC_LEVEL0 = 0, KC_RESIZE, KC_FAST, KC_QUADTREE, KC_DESCRIBE, KC_STEREO, KC_COUNT };
+const char* const kKernelNames[KC_COUNT] = {"k_level0", "k_resize", "k_fast", "k_quadtree", "k_describe", "k_stereo"};
 
 struct TimedSpan { int kc; hipEvent_t a, b; };
 
@@ -69,6 +69,8 @@ struct orbhip_extractor {
     int plan_lanes = 0;            // workspaces allocated for the current plan
     int max_lanes = 1;             // ORBHIP_LANES=2..4: that many passes of a large batch in flight (a few % more throughput)
     hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_order = nullptr;   // orders work of another instance (stereo matching) against this one's stream
+    hipStream_t last_stream = nullptr;   // stream of the last batch call
     int* d_status = nullptr;       // bit0 candidate overflow, bit1 output capacity
     size_t qt_lds = 0;
     int last_pass_frames = 0;
@@ -81,6 +83,8 @@ struct orbhip_extractor {
     size_t d_out_frames = 0; int d_out_cap = 0;
     // stereo matching (owned by the left instance of a pair)
     int* d_st_sad = nullptr; size_t d_st_sad_n = 0;      // [frames][cap] SAD of the match, -1 = none
+    int4* d_st_rinfo = nullptr;                          // [frames][cap] row band / octave / x of the right keypoints, binned by row
+    int* d_st_bins = nullptr; size_t d_st_bins_n = 0;    // [frames][nbins + 1] record range of every row bin
     uint8_t* d_st_tmp = nullptr; size_t d_st_tmp_bytes = 0;   // staging of the host-array entry point
     // timing
     bool timing = false;
@@ -428,7 +432,8 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
         delete e;
         return ORBHIP_ERR_HIP;
     }
-    bool ok = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess;
+    bool ok = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming) == hipSuccess;
     for (Workspace& w : e->ws)
         ok = ok && hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&w.done, hipEventDisableTiming) == hipSuccess;
@@ -446,7 +451,7 @@ int orbhip_destroy(orbhip_extractor* e) {
     for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
     free_plan(e);
     dfree(e->d_status); dfree(e->d_in); dfree(e->d_out_kp); dfree(e->d_out_desc); dfree(e->d_out_cnt);
-    dfree(e->d_st_sad); dfree(e->d_st_tmp);
+    dfree(e->d_st_sad); dfree(e->d_st_rinfo); dfree(e->d_st_bins); dfree(e->d_st_tmp);
     if (e->h_in) (void)hipHostFree(e->h_in);
     if (e->h_out) (void)hipHostFree(e->h_out);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -455,6 +460,7 @@ int orbhip_destroy(orbhip_extractor* e) {
         if (w.done) (void)hipEventDestroy(w.done);
     }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_order) (void)hipEventDestroy(e->ev_order);
     delete e;
     return ORBHIP_OK;
 }
@@ -467,6 +473,7 @@ int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int 
     if (row_stride < (size_t)width) return ORBHIP_ERR_ARG;
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    e->last_stream = s;
     // frames per pass: max_batch, but keep the workspaces (about 20 bytes per input pixel and frame:
     // pyramid planes, FAST output segments, quadtree keys) under ~24 GB
     const double ws_per_frame = 20.0 * (double)width * (double)height;
@@ -528,7 +535,7 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int nframes, 
         e->d_in_bytes = need;
     }
     if (need > e->h_in_bytes) {
-        dfree(e->d_st_sad); dfree(e->d_st_tmp);
+        dfree(e->d_st_sad); dfree(e->d_st_rinfo); dfree(e->d_st_bins); dfree(e->d_st_tmp);
     if (e->h_in) (void)hipHostFree(e->h_in);
         e->h_in = nullptr; e->h_in_bytes = 0;
         HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_in), need, hipHostMallocDefault));
@@ -714,9 +721,19 @@ int orbhip_stereo_match_batch_device(orbhip_extractor* left, orbhip_extractor* r
     const size_t need = (size_t)nframes * cap + (size_t)nframes;   // + a counter per frame when the caller wants none
     if (need > e->d_st_sad_n) {
         HIP_TRY(e, hipDeviceSynchronize());
-        dfree(e->d_st_sad);
+        dfree(e->d_st_sad); dfree(e->d_st_rinfo);
         HIP_TRY(e, hipMalloc(&e->d_st_sad, need * sizeof(int)));
+        HIP_TRY(e, hipMalloc(&e->d_st_rinfo, (size_t)nframes * cap * sizeof(int4)));
         e->d_st_sad_n = need;
+    }
+    // row bins of the right keypoints; a row band is at most 2 * ceil(2 * scale) + 2 rows high
+    const int nbins = (left->plan.lv[0].h >> ST_BIN_SHIFT) + 2;
+    const int band = 2 * (int)std::ceil(2.0f * left->sf.back()) + 2;
+    if ((size_t)nframes * (nbins + 1) > e->d_st_bins_n) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        dfree(e->d_st_bins);
+        HIP_TRY(e, hipMalloc(&e->d_st_bins, (size_t)nframes * (nbins + 1) * sizeof(int)));
+        e->d_st_bins_n = (size_t)nframes * (nbins + 1);
     }
     // the level geometry of the two plans is the same function of (size, parameters); plane
     // offsets depend on the frames a plan was made for, so each side is addressed with its own plan
@@ -724,14 +741,32 @@ int orbhip_stereo_match_batch_device(orbhip_extractor* left, orbhip_extractor* r
         e->err = "left and right instances must be used with the same pass size";
         return ORBHIP_ERR_ARG;
     }
+    // the two extractions may have run on other streams than `s`: wait for them here, and make their
+    // streams wait for the matching before a later pass overwrites the pyramids it reads
+    orbhip_extractor* const sides[2] = {left, right};
+    for (orbhip_extractor* x : sides)
+        if (x->last_stream && x->last_stream != s) {
+            HIP_TRY(e, hipEventRecord(x->ev_order, x->last_stream));
+            HIP_TRY(e, hipStreamWaitEvent(s, x->ev_order, 0));
+        }
+    {
+    SpanGuard t(e, s, KC_STEREO);
+    hipLaunchKernelGGL(k_stereo_prep, dim3(nframes), dim3(256), 0, s,
+                       left->d_plan, reinterpret_cast<const StKp*>(d_kp_r), d_cnt_r, cap, nbins, e->d_st_rinfo, e->d_st_bins);
     hipLaunchKernelGGL(k_stereo_match, dim3((cap + 3) / 4, nframes), dim3(256), 0, s,
-                       left->d_plan, left->ws[left->last_ws].d_pyr, right->ws[right->last_ws].d_pyr,
+                       left->d_plan, e->d_st_rinfo, e->d_st_bins, nbins, band, left->ws[left->last_ws].d_pyr, right->ws[right->last_ws].d_pyr,
                        reinterpret_cast<const StKp*>(d_kp_l), d_desc_l, d_cnt_l,
                        reinterpret_cast<const StKp*>(d_kp_r), d_desc_r, d_cnt_r, cap, mb, mbf, d_uright, d_depth, e->d_st_sad);
     int* nm = d_nmatch;
     hipLaunchKernelGGL(k_stereo_median, dim3(nframes), dim3(256), 0, s, d_cnt_l, cap, e->d_st_sad, d_uright, d_depth,
                        nm ? nm : e->d_st_sad + (size_t)nframes * cap);
+    }
     HIP_TRY(e, hipGetLastError());
+    for (orbhip_extractor* x : sides)
+        if (x->last_stream && x->last_stream != s) {
+            HIP_TRY(e, hipEventRecord(x->ev_order, s));
+            HIP_TRY(e, hipStreamWaitEvent(x->last_stream, x->ev_order, 0));
+        }
     return ORBHIP_OK;
 }
 
