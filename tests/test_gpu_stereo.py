@@ -15,13 +15,7 @@ FX, BF = 718.856, 386.1448          # KITTI 00-02 calibration (Examples/Stereo/K
 
 
 def make_pair(kind, w, h, index, disparities=(3, 12, 40)):
-    left = synth.frame(kind, w, h, index)
-    right = np.empty_like(left)
-    bands = np.array_split(np.arange(h), len(disparities))
-    for rows, d in zip(bands, disparities):
-        right[rows[0]:rows[-1] + 1, :w - d] = left[rows[0]:rows[-1] + 1, d:]
-        right[rows[0]:rows[-1] + 1, w - d:] = left[rows[0]:rows[-1] + 1, w - d:]
-    return left, right
+    return synth.stereo_pair(kind, w, h, index, disparities)
 
 
 def run_pair(kind, w, h, index, params=PARAMS):
@@ -76,3 +70,39 @@ def test_stereo_rejects_mismatched_instances():
     kr, dr = gR(b, fetch_pyramid=False)
     with pytest.raises(orbhip.OrbHipError):
         orbhip.ComputeStereoMatches(gL, gR, kl, dl, kr, dr, BF / FX, BF)
+
+
+def test_stereo_batch_device_matches_oracle():
+    """Device-resident batch entry point: three pairs in one pass, outputs compared per pair."""
+    import torch
+    from oracle import orb_oracle as O
+    from visual_slam_amd import orbhip
+    w, h, prm = 640, 480, (1000, 1.2, 8, 20, 7)
+    pairs = [synth.stereo_pair("blocks", w, h, i, (4, 17)) for i in range(3)]
+    dev = torch.device("cuda", 0)
+    L = torch.from_numpy(np.stack([p[0] for p in pairs])).to(dev)
+    R = torch.from_numpy(np.stack([p[1] for p in pairs])).to(dev)
+    gL, gR = orbhip.ORBextractor(*prm), orbhip.ORBextractor(*prm)
+    cap = gL.max_keypoints()
+    mk = lambda: (torch.empty((3, cap, 7), dtype=torch.float32, device=dev), torch.empty((3, cap, 32), dtype=torch.uint8, device=dev),
+                  torch.zeros((3,), dtype=torch.int32, device=dev))
+    (kl, dl, cl), (kr, dr, cr) = mk(), mk()
+    ur = torch.empty((3, cap), dtype=torch.float32, device=dev)
+    dp = torch.empty((3, cap), dtype=torch.float32, device=dev)
+    nm = torch.zeros((3,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    gL.extract_batch_device(L.data_ptr(), 3, w, h, w, w * h, kl.data_ptr(), dl.data_ptr(), cl.data_ptr(), cap)
+    gR.extract_batch_device(R.data_ptr(), 3, w, h, w, w * h, kr.data_ptr(), dr.data_ptr(), cr.data_ptr(), cap)
+    orbhip.stereo_match_batch_device(gL, gR, 3, kl.data_ptr(), dl.data_ptr(), cl.data_ptr(), kr.data_ptr(), dr.data_ptr(),
+                                     cr.data_ptr(), cap, BF / FX, BF, ur.data_ptr(), dp.data_ptr(), nm.data_ptr())
+    gL.synchronize(); gR.synchronize()
+    torch.cuda.synchronize()
+    for i, (left, right) in enumerate(pairs):
+        oL, oR = O.OracleExtractor(*prm), O.OracleExtractor(*prm)
+        okl, odl = oL.extract(left)
+        okr, odr = oR.extract(right)
+        ou, od, on = O.stereo_match(oL, oR, okl, odl, okr, odr, BF / FX, BF)
+        n = int(cl[i].item())
+        assert n == len(okl) and int(nm[i].item()) == on
+        assert np.array_equal(ur[i, :n].cpu().numpy().view(np.uint32), ou.view(np.uint32))
+        assert np.array_equal(dp[i, :n].cpu().numpy().view(np.uint32), od.view(np.uint32))

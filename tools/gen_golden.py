@@ -38,3 +38,23 @@ for name, kind, w, h, idx, prm in CASES:
     np.savez_compressed(out / (name + ".npz"), image=img, params=np.array(prm, np.float64), keypoints=kp,
                         descriptors=desc, level_crc32=crcs, candidates_per_level=ncand)
     print(name, len(kp), ncand.tolist())
+
+
+# ---- stereo matching (oracle restatement of reference src/Frame.cc:481-653): tests/golden/stereo/*.npz
+STEREO_CASES = [
+    # name, kind, w, h, index, disparities per horizontal band, extractor parameters
+    ("blocks_320x240", "blocks", 320, 240, 21, (3, 9, 20), (400, 1.2, 6, 20, 7)),
+    ("lowc_288x216", "lowc", 288, 216, 22, (5,), (300, 1.2, 4, 20, 7)),
+]
+FX, BF = 718.856, 386.1448          # Examples/Stereo/KITTI00-02.yaml
+sout = out / "stereo"
+sout.mkdir(exist_ok=True)
+for name, kind, w, h, idx, disps, prm in STEREO_CASES:
+    left, right = synth.stereo_pair(kind, w, h, idx, disps)
+    eL, eR = O.OracleExtractor(*prm), O.OracleExtractor(*prm)
+    kl, dl = eL.extract(left)
+    kr, dr = eR.extract(right)
+    ur, dp, kept = O.stereo_match(eL, eR, kl, dl, kr, dr, BF / FX, BF)
+    np.savez_compressed(sout / (name + ".npz"), left=left, right=right, params=np.array(prm, np.float64),
+                        mb=np.float32(BF / FX), mbf=np.float32(BF), uright=ur, depth=dp, kept=np.int32(kept))
+    print("stereo", name, len(kl), len(kr), kept)

@@ -39,3 +39,15 @@ def frame(kind, w, h, index=0):
 
 def batch(kind, w, h, n, start=0):
     return np.stack([frame(kind, w, h, start + i) for i in range(n)])
+
+
+def stereo_pair(kind, w, h, index=0, disparities=(3, 12, 40)):
+    """A rectified synthetic pair: the right image is the left one with the content of each
+    horizontal band moved left by that band's disparity (the vacated columns keep the left pixels)."""
+    left = frame(kind, w, h, index)
+    right = np.empty_like(left)
+    for rows, d in zip(np.array_split(np.arange(h), len(disparities)), disparities):
+        r0, r1 = rows[0], rows[-1] + 1
+        right[r0:r1, :w - d] = left[r0:r1, d:]
+        right[r0:r1, w - d:] = left[r0:r1, w - d:]
+    return left, right
