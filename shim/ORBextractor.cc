@@ -98,4 +98,26 @@ void ORBextractor::operator()( cv::InputArray _image, cv::InputArray _mask, std:
     }
 }
 
+// Frame::ComputeStereoMatches (reference src/Frame.cc:481-653)
+void ORBextractor::ComputeStereoMatches(ORBextractor& left, ORBextractor& right,
+                                        const std::vector<cv::KeyPoint>& keysLeft, const cv::Mat& descLeft,
+                                        const std::vector<cv::KeyPoint>& keysRight, const cv::Mat& descRight,
+                                        float mb, float mbf, std::vector<float>& uRight, std::vector<float>& depth)
+{
+    const int nl = (int)keysLeft.size(), nr = (int)keysRight.size();
+    uRight.assign(nl, -1.0f);                                  // src/Frame.cc:483-484
+    depth.assign(nl, -1.0f);
+    if (nl == 0) return;
+    // descriptor rows are 32 contiguous bytes each; a Mat may pad rows, so pack them
+    std::vector<unsigned char> dl((size_t)nl * 32), dr((size_t)(nr > 0 ? nr : 1) * 32);
+    for (int i = 0; i < nl; i++) std::memcpy(&dl[(size_t)i * 32], descLeft.ptr(i), 32);
+    for (int i = 0; i < nr; i++) std::memcpy(&dr[(size_t)i * 32], descRight.ptr(i), 32);
+    int kept = 0;
+    check(orbhip_stereo_match(left.mpHandle, right.mpHandle,
+                              reinterpret_cast<const orbhip_keypoint*>(keysLeft.data()), dl.data(), nl,
+                              reinterpret_cast<const orbhip_keypoint*>(keysRight.data()), dr.data(), nr,
+                              mb, mbf, uRight.data(), depth.data(), &kept),
+          left.mpHandle, "stereo_match");
+}
+
 } //namespace ORB_SLAM

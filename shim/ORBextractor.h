@@ -69,6 +69,15 @@ public:
 
     void SetPyramidFetch(bool on) { mbFetchPyramid = on; }
 
+    // Frame::ComputeStereoMatches (reference src/Frame.cc:481-653) on the GPU, for the pair of images
+    // the two instances extracted last: fills mvuRight / mvDepth (-1 = no match). With it the body
+    // of Frame::ComputeStereoMatches is one call and the pyramids need not be fetched
+    // (SetPyramidFetch(false)).
+    static void ComputeStereoMatches(ORBextractor& left, ORBextractor& right,
+                                     const std::vector<cv::KeyPoint>& keysLeft, const cv::Mat& descLeft,
+                                     const std::vector<cv::KeyPoint>& keysRight, const cv::Mat& descRight,
+                                     float mb, float mbf, std::vector<float>& uRight, std::vector<float>& depth);
+
 private:
     ORBextractor(const ORBextractor&);
     ORBextractor& operator=(const ORBextractor&);

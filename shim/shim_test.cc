@@ -62,6 +62,39 @@ int main()
         CHECK(std::memcmp(m.data - 19 * m.step - 19, ref.data(), ref.size()) == 0);
         CHECK(m.ptr(5)[-3] == m.ptr(5)[3] && m.ptr(-2)[7] == m.ptr(2)[7]);
     }
+    // stereo matching through the class against the oracle's restatement of Frame::ComputeStereoMatches
+    {
+        const int d = 9;
+        cv::Mat imgR(H, W, CV_8UC1);
+        for (int y = 0; y < H; y++) {
+            std::memcpy(imgR.ptr(y), img.ptr(y) + d, (size_t)(W - d));
+            std::memcpy(imgR.ptr(y) + (W - d), img.ptr(y) + (W - d), (size_t)d);
+        }
+        ORB_SLAM2::ORBextractor exR(1200, 1.2f, 8, 20, 7);
+        std::vector<cv::KeyPoint> kpsR;
+        cv::Mat descR;
+        exR(imgR, cv::Mat(), kpsR, descR);
+        const float fx = 435.2f, bf = 47.9f;
+        std::vector<float> uR, dep;
+        ORB_SLAM2::ORBextractor::ComputeStereoMatches(ex, exR, kps, desc, kpsR, descR, bf / fx, bf, uR, dep);
+        orbo_extractor* oR = orbo_create(1200, 1.2f, 8, 20, 7, ORBO_BLUR_LEGACY, ORBO_TIE_CREATION_ORDER, ORBO_FMA_OFF);
+        std::vector<orbo_keypoint> okpR(4096);
+        std::vector<unsigned char> odescR(4096 * 32);
+        int onR = 0;
+        CHECK(orbo_extract(oR, imgR.data, W, H, imgR.step, okpR.data(), 4096, &onR, odescR.data()) == 0);
+        CHECK(onR == (int)kpsR.size());
+        std::vector<float> ouR(on), odep(on);
+        const int okept = orbo_stereo_match(o, oR, okp.data(), odesc.data(), on, okpR.data(), odescR.data(), onR, bf / fx, bf,
+                                            ouR.data(), odep.data());
+        int matched = 0;
+        for (int i = 0; i < on; i++) {
+            CHECK(std::memcmp(&uR[i], &ouR[i], 4) == 0 && std::memcmp(&dep[i], &odep[i], 4) == 0);
+            matched += uR[i] >= 0;
+        }
+        CHECK(matched == okept && matched > 200);
+        orbo_destroy(oR);
+        std::printf("shim stereo ok: %d of %d left keypoints matched\n", matched, on);
+    }
     // empty input leaves the outputs untouched; second call replaces them
     std::vector<cv::KeyPoint> keep = kps;
     ex(cv::Mat(), cv::Mat(), kps, desc);
