@@ -284,10 +284,30 @@ def main():
             from oracle import orb_oracle   # checker / baseline only, never on the measured GPU path
             from visual_slam_amd import synth
             nthreads = min(16, os.cpu_count() or 1)
-            sample = synth.batch(args.kind, w, h, args.cpu_frames)
-            secs, ccounts = orb_oracle.extract_batch_mt((nfeat, scale, levels, ini_th, min_th), sample, nthreads)
-            cpu = {"value": round(args.cpu_frames / secs, 2), "unit": "frames/s", "cores": nthreads, "kind": "port",
-                   "sample": "%d %s frames of %s, one oracle instance per thread" % (args.cpu_frames, args.kind, args.workload)}
+            if args.stereo:
+                # pairs dealt to worker threads (ctypes releases the GIL), each with its own two oracle instances
+                from concurrent.futures import ThreadPoolExecutor
+                npairs = max(args.cpu_frames // 2, 1)
+                pairs = [synth.stereo_pair(args.kind, w, h, i, (12,)) for i in range(npairs)]
+                prm = (nfeat, scale, levels, ini_th, min_th)
+
+                def work(t):
+                    eL, eR = orb_oracle.OracleExtractor(*prm), orb_oracle.OracleExtractor(*prm)
+                    for left, right in pairs[t::nthreads]:
+                        kl, dl = eL.extract(left)
+                        kr, dr = eR.extract(right)
+                        orb_oracle.stereo_match(eL, eR, kl, dl, kr, dr, bf / fx, bf)
+                t1 = time.perf_counter()
+                with ThreadPoolExecutor(nthreads) as pool:
+                    list(pool.map(work, range(nthreads)))
+                secs = time.perf_counter() - t1
+                cpu = {"value": round(npairs / secs, 2), "unit": "pairs/s", "cores": nthreads, "kind": "port",
+                       "sample": "%d %s pairs of %s, two oracle instances per thread" % (npairs, args.kind, args.workload)}
+            else:
+                sample = synth.batch(args.kind, w, h, args.cpu_frames)
+                secs, ccounts = orb_oracle.extract_batch_mt((nfeat, scale, levels, ini_th, min_th), sample, nthreads)
+                cpu = {"value": round(args.cpu_frames / secs, 2), "unit": "frames/s", "cores": nthreads, "kind": "port",
+                       "sample": "%d %s frames of %s, one oracle instance per thread" % (args.cpu_frames, args.kind, args.workload)}
         extra = {}
         if args.host_fed:
             host = frames[:min(B, 64)].cpu().numpy()

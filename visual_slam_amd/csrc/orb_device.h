@@ -75,3 +75,27 @@ struct LevelKp {              // keypoint of one level after the quadtree, level
     uint16_t score;
     uint16_t pad;
 };
+
+// Division of a workgroup index by a grid extent d through a multiply: m = ceil(2^32 / d) (0 for
+// d == 1) gives n / d == umulhi(n, m) whenever n * d < 2^32, which holds for every grid here
+// (n < 2^24 workgroups, d < 2^8 tiles per row or column).
+static inline unsigned grid_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
+
+#ifdef __HIPCC__
+// Workgroups are dealt to the 8 XCDs (each with its own L2) round-robin in dispatch order, so
+// tiles that are neighbours in the image would land on different L2s and each fetch the rows and
+// cache lines they share from memory again. This remap gives every group of workgroups that
+// share an XCD a contiguous range of the (x, y, z) grid instead (x fastest). It is a bijection of
+// the grid for any size; a wrong guess about placement costs speed, never correctness.
+// mx / my: grid_magic(gridDim.x / .y) from the host, so that the remap is a few scalar multiplies.
+__device__ __forceinline__ void xcd_tile(unsigned mx, unsigned my, int& bx, int& by, int& bz) {
+    const unsigned gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+    const unsigned orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const unsigned t = mx ? __umulhi(id, mx) : id;
+    bx = (int)(id - t * gx);
+    bz = (int)(my ? __umulhi(t, my) : t);
+    by = (int)(t - (unsigned)bz * gy);
+}
+#endif

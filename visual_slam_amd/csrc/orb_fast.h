@@ -142,7 +142,7 @@ __device__ __forceinline__ void fast_score_queue(const uint16_t* queue, int n, i
 __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, LevelGeom g, int min_th,
                                               unsigned long long seg_per_frame, int segc_per_frame,
                                               uint2* __restrict__ seg, int* __restrict__ seg_count,
-                                              int* __restrict__ status) {
+                                              int* __restrict__ status, unsigned magic_x, unsigned magic_y) {
     __shared__ __align__(16) uint8_t s_map[FT_MAP_ROWS * FT_P];
     __shared__ __align__(16) uint8_t s_img[FT_IMG_ROWS * FT_P];
     __shared__ uint16_t s_queue[4][FT_QUEUE];
@@ -150,9 +150,10 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: row bookkeeping runs on the scalar unit
-    const int f = blockIdx.z;
-    const int xs = ORB_MINB + FT_COLS * (int)blockIdx.x;       // level x of the tile's first output column
-    const int y0 = ORB_EDGE + FT_ROWS * (int)blockIdx.y;       // level y of the tile's first row
+    int bx, by, f;
+    xcd_tile(magic_x, magic_y, bx, by, f);                     // neighbouring tiles (shared halo rows / lines) share an L2
+    const int xs = ORB_MINB + FT_COLS * bx;                    // level x of the tile's first output column
+    const int y0 = ORB_EDGE + FT_ROWS * by;                    // level y of the tile's first row
     const int x_hi = g.w - ORB_EDGE, y_hi = g.h - ORB_EDGE;    // detectable area [19, x_hi) x [19, y_hi)
     const int xg = xs - 4 + 4 * lane;                          // level x of this lane's pixel 0
     const int col = ORB_OX + xg;                               // device column, multiple of 4
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
     __syncthreads();                                           // all scores of the tile are in the map
 
     // ---- non-maximum suppression inside the cell and emission, map rows 1+8*wv .. 8+8*wv
-    const int segi = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 4 + wv;
+    const int segi = (by * (int)gridDim.x + bx) * 4 + wv;
     uint2* out = seg + (size_t)f * seg_per_frame + g.seg_off + (size_t)segi * FT_SEGCAP;
     int nout = 0;
     const int mh = 1 + 8 * wv;

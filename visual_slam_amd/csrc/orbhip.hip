@@ -326,8 +326,9 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
         SpanGuard t(e, s, KC_RESIZE);
         const LevelGeom& g = P.lv[l];
         const int ndw = (ORB_OX + g.w + ORB_EDGE + 3) / 4;
-        hipLaunchKernelGGL(k_resize, dim3((ndw + 63) / 64, (g.rows + 4 * RS_RPT - 1) / (4 * RS_RPT), frames), blk2, 0, s,
-                           W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g, e->d_tabs, ndw);
+        const dim3 grid((ndw + 63) / 64, (g.rows + 4 * RS_RPT - 1) / (4 * RS_RPT), frames);
+        hipLaunchKernelGGL(k_resize, grid, blk2, 0, s, W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g,
+                           e->d_tabs, ndw);
     }
     for (int l = 0; l < nl; l++) {
         const LevelGeom& g = P.lv[l];
@@ -335,7 +336,7 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
         SpanGuard t(e, s, KC_FAST);
         hipLaunchKernelGGL(k_fast, dim3(g.ntx, g.nty, frames), dim3(256), 0, s,
                            W.d_pyr, g, P.min_th, P.seg_per_frame, P.segc_per_frame,
-                           W.d_seg, W.d_seg_count, e->d_status);
+                           W.d_seg, W.d_seg_count, e->d_status, grid_magic(g.ntx), grid_magic(g.nty));
     }
     {
         SpanGuard t(e, s, KC_QUADTREE);
