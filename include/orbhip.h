@@ -88,6 +88,18 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int nframes, 
                          size_t row_stride, size_t frame_stride, orbhip_keypoint* kp, uint8_t* desc,
                          int* counts, int cap);
 
+/* The same two calls for interleaved 8-bit colour images: the cvtColor to gray that precedes the
+ * extraction in the reference (Tracking::GrabImageStereo / GrabImageRGBD / GrabImageMonocular,
+ * src/Tracking.cc:166-191,211-222,249-262: CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY)
+ * happens on the device while the level-0 plane is written, in the 8-bit arithmetic of OpenCV
+ * 2.4 .. 3.x (gray = (B*1868 + G*9617 + R*4899 + 8192) >> 14). channels is 3 or 4 (alpha ignored),
+ * rgb != 0 means channel 0 is red (mbRGB, src/Tracking.cc:126-131). Strides are in bytes. */
+int orbhip_extract_color(orbhip_extractor* e, const uint8_t* img, int width, int height, size_t stride,
+                         int channels, int rgb, orbhip_keypoint* kp, int cap, int* n, uint8_t* desc);
+int orbhip_extract_batch_device_color(orbhip_extractor* e, const uint8_t* d_imgs, int nframes, int width,
+                                      int height, size_t row_stride, size_t frame_stride, int channels, int rgb,
+                                      orbhip_keypoint* d_kp, uint8_t* d_desc, int* d_counts, int cap, void* stream);
+
 /* Waits for everything enqueued by the handle; reports a deferred capacity/geometry error. */
 int orbhip_synchronize(orbhip_extractor* e);
 

@@ -885,4 +885,21 @@ int orbo_stereo_match(const orbo_extractor* L, const orbo_extractor* R,
     return kept;
 }
 
+/* cv::cvtColor(src, dst, CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY) for 8-bit images, the
+ * conversion the reference applies before extraction (src/Tracking.cc:166-191, 211-222, 249-262).
+ * OpenCV 2.4 .. 3.x fixed point: yuv_shift = 14, R2Y = 4899, G2Y = 9617, B2Y = 1868, rounding term
+ * 1 << 13 (RGB2Gray<uchar> in imgproc/src/color.cpp). OpenCV 4 uses 15-bit weights instead; the
+ * reference is built against 2.4 / 3.x (CMakeLists.txt:31-37). */
+void orbo_cvt_gray(const uint8_t* src, int w, int h, size_t sstride, int channels, int rgb,
+                   uint8_t* dst, size_t dstride) {
+    for (int y = 0; y < h; y++) {
+        const uint8_t* s = src + (size_t)y * sstride;
+        uint8_t* d = dst + (size_t)y * dstride;
+        for (int x = 0; x < w; x++, s += channels) {
+            const int r = rgb ? s[0] : s[2], g = s[1], b = rgb ? s[2] : s[0];
+            d[x] = (uint8_t)((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14);
+        }
+    }
+}
+
 } // extern "C"

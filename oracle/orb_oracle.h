@@ -96,6 +96,11 @@ double orbo_extract_batch_mt(int nfeatures, float scale_factor, int nlevels, int
                              int w, int h, size_t row_stride, size_t frame_stride, int nthreads,
                              int* counts);
 
+/* cv::cvtColor to gray of an interleaved 3- or 4-channel 8-bit image (src/Tracking.cc:166-191);
+ * rgb != 0: channel 0 is red. OpenCV 2.4 .. 3.x 14-bit fixed point. */
+void orbo_cvt_gray(const uint8_t* src, int w, int h, size_t sstride, int channels, int rgb,
+                   uint8_t* dst, size_t dstride);
+
 /* Frame::ComputeStereoMatches (reference src/Frame.cc:481-653) on the last extractions of a left and
  * a right instance: kl/dl/nl and kr/dr/nr are their keypoints and descriptors, mb / mbf the stereo
  * baseline (metres) and baseline times fx. uright[nl] / depth[nl] receive mvuRight / mvDepth

@@ -72,6 +72,7 @@ def lib():
                                             C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, i32p]
         L.orbo_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.orbo_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -168,6 +169,15 @@ def stereo_match(left, right, kp_l, desc_l, kp_r, desc_r, mb, mbf):
     if n < 0:
         raise RuntimeError("orbo_stereo_match failed: %d" % n)
     return uright[:len(kp_l)], depth[:len(kp_l)], n
+
+
+def cvt_gray(img, rgb):
+    """cv::cvtColor(img, CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY) of an (H, W, 3|4) uint8 image."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w, cn = img.shape
+    out = np.zeros((h, w), np.uint8)
+    lib().orbo_cvt_gray(_ptr(img), w, h, img.strides[0], cn, int(bool(rgb)), _ptr(out), out.strides[0])
+    return out
 
 
 def resize_linear_u8(src, dw, dh):

@@ -71,6 +71,53 @@ __global__ __launch_bounds__(256) void k_level0_edges(const uint8_t* __restrict_
     reinterpret_cast<uint4*>(D)[c16] = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// Level 0 from an interleaved 3- or 4-channel 8-bit image: the cvtColor(..., CV_RGB2GRAY / CV_BGR2GRAY /
+// CV_RGBA2GRAY / CV_BGRA2GRAY) that precedes extraction in the reference (src/Tracking.cc:166-191,
+// 211-222, 249-262) fused into the border copy. 8-bit arithmetic of OpenCV 2.4 .. 3.x:
+// gray = (B * 1868 + G * 9617 + R * 4899 + 8192) >> 14. One thread per (row, 16-pixel group); groups
+// inside the image with a 16-byte aligned source read CN dwordx4, the others go pixel by pixel
+// through the reflection.
+__device__ __forceinline__ uint32_t gray14(uint32_t c0, uint32_t c1, uint32_t c2, bool rgb) {
+    const uint32_t r = rgb ? c0 : c2, b = rgb ? c2 : c0;
+    return (b * 1868u + c1 * 9617u + r * 4899u + 8192u) >> 14;
+}
+
+template <int CN>
+__global__ __launch_bounds__(256) void k_level0_color(const uint8_t* __restrict__ src, size_t row_stride, size_t frame_stride,
+                                                      uint8_t* __restrict__ pyr, LevelGeom g, int n16, int rgb, int aligned16) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int f = blockIdx.y;
+    const int r = i / n16;
+    if (r >= g.rows) return;
+    const int c16 = i - r * n16;
+    const uint8_t* S = src + (size_t)f * frame_stride + (size_t)reflect101(r - ORB_OY, g.h) * row_stride;
+    const int x0 = c16 * 16 - ORB_OX;
+    uint32_t o[4] = {0, 0, 0, 0};
+    if (aligned16 && x0 >= 0 && x0 + 16 <= g.w) {
+        uint32_t w[4 * CN];
+#pragma unroll
+        for (int k = 0; k < CN; k++) {
+            const uint4 v = reinterpret_cast<const uint4*>(S + (size_t)x0 * CN)[k];
+            w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+        }
+#pragma unroll
+        for (int d = 0; d < 16; d++) {
+            uint32_t c[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const int byte = d * CN + k; c[k] = (w[byte >> 2] >> (8 * (byte & 3))) & 0xFF; }
+            o[d >> 2] |= gray14(c[0], c[1], c[2], rgb != 0) << (8 * (d & 3));
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < 16; d++) {
+            const uint8_t* p = S + (size_t)reflect101(x0 + d, g.w) * CN;
+            o[d >> 2] |= gray14(p[0], p[1], p[2], rgb != 0) << (8 * (d & 3));
+        }
+    }
+    uint8_t* D = pyr + g.pyr_off + (size_t)f * g.plane_bytes + (size_t)r * g.pitch;
+    reinterpret_cast<uint4*>(D)[c16] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Level l from level l-1: cv::resize(8UC1, INTER_LINEAR) fixed-point arithmetic, border included
 // (a border pixel is the resized value at the reflected coordinate, which is what copyMakeBorder

@@ -298,8 +298,9 @@ struct SpanGuard {   // records a pair of events around a group of launches when
 };
 
 // One pass: `frames` frames starting at device pointer d_imgs; outputs written at frame index frame0.
+// channels: 1 (gray), 3 or 4 (interleaved colour, converted to gray on the way in); rgb: channel 0 is red.
 int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_imgs, int frames, size_t row_stride,
-             size_t frame_stride, float* d_kp, uint8_t* d_desc, int* d_counts, int cap, int frame0) {
+             size_t frame_stride, int channels, int rgb, float* d_kp, uint8_t* d_desc, int* d_counts, int cap, int frame0) {
     const PlanDev& P = e->plan;
     const int nl = P.nlevels;
     const dim3 blk2(64, 4);
@@ -311,7 +312,13 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
         // 16-byte groups [i_lo, i_hi) lie inside the image: straight dwordx4 copies when the
         // source is aligned; the groups that touch the border go through the reflecting byte path
         const int i_lo = ORB_OX / 16, i_hi = (ORB_OX + g.w) / 16;
-        if (aligned16 && i_hi > i_lo && g.h > ORB_EDGE && g.w > ORB_OX) {
+        if (channels != 1) {
+            const dim3 grid((g.rows * n16 + 255) / 256, frames);
+            if (channels == 3)
+                hipLaunchKernelGGL(k_level0_color<3>, grid, dim3(256), 0, s, d_imgs, row_stride, frame_stride, W.d_pyr, g, n16, rgb, aligned16);
+            else
+                hipLaunchKernelGGL(k_level0_color<4>, grid, dim3(256), 0, s, d_imgs, row_stride, frame_stride, W.d_pyr, g, n16, rgb, aligned16);
+        } else if (aligned16 && i_hi > i_lo && g.h > ORB_EDGE && g.w > ORB_OX) {
             hipLaunchKernelGGL(k_level0_interior, dim3((i_hi - i_lo + 63) / 64, (g.rows + 4 * L0_RPT - 1) / (4 * L0_RPT), frames), blk2, 0, s,
                                d_imgs, row_stride, frame_stride, W.d_pyr, g, i_lo, i_hi);
             const int nb = n16 - (i_hi - i_lo);
@@ -466,12 +473,13 @@ int orbhip_destroy(orbhip_extractor* e) {
     return ORBHIP_OK;
 }
 
-int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int nframes, int width, int height,
-                                size_t row_stride, size_t frame_stride, orbhip_keypoint* d_kp, uint8_t* d_desc,
-                                int* d_counts, int cap, void* stream) {
-    if (!e || !d_kp || !d_desc || !d_counts || cap < 1 || nframes < 0) return ORBHIP_ERR_ARG;
+static int extract_device_impl(orbhip_extractor* e, const uint8_t* d_imgs, int nframes, int width, int height,
+                               size_t row_stride, size_t frame_stride, int channels, int rgb, orbhip_keypoint* d_kp,
+                               uint8_t* d_desc, int* d_counts, int cap, void* stream) {
+    if (!e || !d_kp || !d_desc || !d_counts || cap < 1 || nframes < 0 || (channels != 1 && channels != 3 && channels != 4))
+        return ORBHIP_ERR_ARG;
     if (!d_imgs || width <= 0 || height <= 0 || nframes == 0) return ORBHIP_ERR_EMPTY;
-    if (row_stride < (size_t)width) return ORBHIP_ERR_ARG;
+    if (row_stride < (size_t)width * channels) return ORBHIP_ERR_ARG;
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     e->last_stream = s;
@@ -501,7 +509,7 @@ int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int 
         const int n = std::min(chunk, nframes - f0);
         Workspace& W = e->ws[pass % lanes];
         int rc = run_pass(e, W, lanes > 1 ? W.stream : s, d_imgs + (size_t)f0 * frame_stride, n, row_stride, frame_stride,
-                          reinterpret_cast<float*>(d_kp), d_desc, d_counts, cap, f0);
+                          channels, rgb, reinterpret_cast<float*>(d_kp), d_desc, d_counts, cap, f0);
         if (rc) return rc;
     }
     if (lanes > 1)
@@ -512,6 +520,20 @@ int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int 
     return ORBHIP_OK;
 }
 
+int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int nframes, int width, int height,
+                                size_t row_stride, size_t frame_stride, orbhip_keypoint* d_kp, uint8_t* d_desc,
+                                int* d_counts, int cap, void* stream) {
+    return extract_device_impl(e, d_imgs, nframes, width, height, row_stride, frame_stride, 1, 0, d_kp, d_desc, d_counts, cap, stream);
+}
+
+int orbhip_extract_batch_device_color(orbhip_extractor* e, const uint8_t* d_imgs, int nframes, int width, int height,
+                                      size_t row_stride, size_t frame_stride, int channels, int rgb,
+                                      orbhip_keypoint* d_kp, uint8_t* d_desc, int* d_counts, int cap, void* stream) {
+    if (channels != 3 && channels != 4) return ORBHIP_ERR_ARG;
+    return extract_device_impl(e, d_imgs, nframes, width, height, row_stride, frame_stride, channels, rgb != 0, d_kp, d_desc,
+                               d_counts, cap, stream);
+}
+
 int orbhip_synchronize(orbhip_extractor* e) {
     if (!e) return ORBHIP_ERR_ARG;
     HIP_TRY(e, hipSetDevice(e->device));
@@ -520,14 +542,15 @@ int orbhip_synchronize(orbhip_extractor* e) {
     return check_status(e);
 }
 
-int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int nframes, int width, int height,
-                         size_t row_stride, size_t frame_stride, orbhip_keypoint* kp, uint8_t* desc,
-                         int* counts, int cap) {
-    if (!e || !kp || !desc || !counts || cap < 1 || nframes < 0) return ORBHIP_ERR_ARG;
+static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nframes, int width, int height,
+                             size_t row_stride, size_t frame_stride, int channels, int rgb, orbhip_keypoint* kp,
+                             uint8_t* desc, int* counts, int cap) {
+    if (!e || !kp || !desc || !counts || cap < 1 || nframes < 0 || (channels != 1 && channels != 3 && channels != 4))
+        return ORBHIP_ERR_ARG;
     if (!imgs || width <= 0 || height <= 0 || nframes == 0) return ORBHIP_ERR_EMPTY;
-    if (row_stride < (size_t)width) return ORBHIP_ERR_ARG;
+    if (row_stride < (size_t)width * channels) return ORBHIP_ERR_ARG;
     HIP_TRY(e, hipSetDevice(e->device));
-    const size_t dev_row = (size_t)(width + 3) & ~(size_t)3, dev_frame = dev_row * height;
+    const size_t dev_row = ((size_t)width * channels + 15) & ~(size_t)15, dev_frame = dev_row * height;
     const size_t need = dev_frame * nframes;
     if (need > e->d_in_bytes) {
         HIP_TRY(e, hipDeviceSynchronize());
@@ -563,11 +586,11 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int nframes, 
         const uint8_t* src = imgs + (size_t)f * frame_stride;
         uint8_t* dst = e->h_in + (size_t)f * dev_frame;
         if (row_stride == dev_row) std::memcpy(dst, src, dev_frame);
-        else for (int y = 0; y < height; y++) std::memcpy(dst + (size_t)y * dev_row, src + (size_t)y * row_stride, (size_t)width);
+        else for (int y = 0; y < height; y++) std::memcpy(dst + (size_t)y * dev_row, src + (size_t)y * row_stride, (size_t)width * channels);
     }
     HIP_TRY(e, hipMemcpyAsync(e->d_in, e->h_in, need, hipMemcpyHostToDevice, e->stream));
-    int rc = orbhip_extract_batch_device(e, e->d_in, nframes, width, height, dev_row, dev_frame,
-                                         reinterpret_cast<orbhip_keypoint*>(e->d_out_kp), e->d_out_desc, e->d_out_cnt, cap, nullptr);
+    int rc = extract_device_impl(e, e->d_in, nframes, width, height, dev_row, dev_frame, channels, rgb,
+                                 reinterpret_cast<orbhip_keypoint*>(e->d_out_kp), e->d_out_desc, e->d_out_cnt, cap, nullptr);
     if (rc) return rc;
     uint8_t* h_cnt = e->h_out, *h_kp = e->h_out + cnt_bytes, *h_desc = h_kp + kp_bytes;
     HIP_TRY(e, hipMemcpyAsync(h_cnt, e->d_out_cnt, (size_t)nframes * sizeof(int), hipMemcpyDeviceToHost, e->stream));
@@ -587,11 +610,27 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int nframes, 
     return ORBHIP_OK;
 }
 
+int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int nframes, int width, int height,
+                         size_t row_stride, size_t frame_stride, orbhip_keypoint* kp, uint8_t* desc,
+                         int* counts, int cap) {
+    return extract_host_impl(e, imgs, nframes, width, height, row_stride, frame_stride, 1, 0, kp, desc, counts, cap);
+}
+
 int orbhip_extract(orbhip_extractor* e, const uint8_t* img, int width, int height, size_t stride,
                    orbhip_keypoint* kp, int cap, int* n, uint8_t* desc) {
     if (!e || !n) return ORBHIP_ERR_ARG;
     int count = 0;
-    int rc = orbhip_extract_batch(e, img, 1, width, height, stride, stride * (size_t)std::max(height, 0), kp, desc, &count, cap);
+    int rc = extract_host_impl(e, img, 1, width, height, stride, stride * (size_t)std::max(height, 0), 1, 0, kp, desc, &count, cap);
+    if (rc == ORBHIP_OK) *n = count;
+    return rc;
+}
+
+int orbhip_extract_color(orbhip_extractor* e, const uint8_t* img, int width, int height, size_t stride, int channels, int rgb,
+                         orbhip_keypoint* kp, int cap, int* n, uint8_t* desc) {
+    if (!e || !n || (channels != 3 && channels != 4)) return ORBHIP_ERR_ARG;
+    int count = 0;
+    int rc = extract_host_impl(e, img, 1, width, height, stride, stride * (size_t)std::max(height, 0), channels, rgb != 0, kp, desc,
+                               &count, cap);
     if (rc == ORBHIP_OK) *n = count;
     return rc;
 }

@@ -31,6 +31,7 @@ EXPORTS = [
     "orbhip_get_features_per_level", "orbhip_get_umax", "orbhip_pyramid_info", "orbhip_pyramid_copy",
     "orbhip_debug_candidates", "orbhip_enable_timing", "orbhip_get_timing", "orbhip_strerror",
     "orbhip_last_error", "orbhip_stereo_match", "orbhip_stereo_match_batch_device",
+    "orbhip_extract_color", "orbhip_extract_batch_device_color",
 ]
 
 
@@ -83,6 +84,9 @@ def lib():
         L.orbhip_strerror.restype = C.c_char_p
         L.orbhip_last_error.argtypes = [vp]
         L.orbhip_last_error.restype = C.c_char_p
+        L.orbhip_extract_color.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, vp, C.c_int, ip, vp]
+        L.orbhip_extract_batch_device_color.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
+                                                        vp, vp, vp, C.c_int, vp]
         L.orbhip_stereo_match.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, ip]
         L.orbhip_stereo_match_batch_device.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float,
                                                        vp, vp, vp, vp]
@@ -163,6 +167,21 @@ class ORBextractor:
         desc = np.zeros((cap, 32), np.uint8)
         n = C.c_int(0)
         self._check(lib().orbhip_extract(self._h, _ptr(image), w, h, image.strides[0], _ptr(kp), cap, C.byref(n), _ptr(desc)))
+        if fetch_pyramid:
+            self.mvImagePyramid = [self.pyramid_level(l) for l in range(self.nlevels)]
+        return kp[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_color(self, image, rgb, fetch_pyramid=True):
+        """operator() on an (H, W, 3|4) uint8 image, with the cvtColor to gray of
+        Tracking::GrabImage* (reference src/Tracking.cc:166-191) done on the device; rgb = mbRGB."""
+        image = np.ascontiguousarray(image, np.uint8)
+        h, w, cn = image.shape
+        cap = self.max_keypoints()
+        kp = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        self._check(lib().orbhip_extract_color(self._h, _ptr(image), w, h, image.strides[0], cn, int(bool(rgb)), _ptr(kp), cap,
+                                               C.byref(n), _ptr(desc)))
         if fetch_pyramid:
             self.mvImagePyramid = [self.pyramid_level(l) for l in range(self.nlevels)]
         return kp[:n.value].copy(), desc[:n.value].copy()
