@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--kind", default="blocks", choices=["blocks", "noise", "lowc"])
     ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--stereo", action="store_true", help="step = left + right extraction + stereo matching of every pair; value = pairs/s")
+    ap.add_argument("--color", type=int, default=0, choices=[0, 3, 4], help="feed interleaved BGR(A) frames: gray conversion fused into level 0")
     ap.add_argument("--host-fed", action="store_true", help="also time the PCIe-inclusive host-buffer entry point")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for the barrier / max-time reduction")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses GPU 0 (use with --backend gloo)")
@@ -177,9 +178,18 @@ def main():
         d_nm = torch.zeros((B,), dtype=torch.int32, device=device)
         fx, bf = 718.856, 386.1448
 
+    if args.color:
+        # gray replicated into every channel: the conversion returns the same gray image
+        # (the weights sum to 2^14), so keypoint counts and later kernels stay comparable
+        frames_c = frames.unsqueeze(-1).expand(B, h, w, args.color).contiguous()
+
     def step():
-        ex.extract_batch_device(frames.data_ptr(), B, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(),
-                                d_cnt.data_ptr(), cap, stream.cuda_stream)
+        if args.color:
+            ex.extract_batch_device_color(frames_c.data_ptr(), B, w, h, w * args.color, w * h * args.color, args.color, 0,
+                                          d_kp.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(), cap, stream.cuda_stream)
+        else:
+            ex.extract_batch_device(frames.data_ptr(), B, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(),
+                                    d_cnt.data_ptr(), cap, stream.cuda_stream)
         if args.stereo:
             exr.extract_batch_device(frames_r.data_ptr(), B, w, h, w, w * h, r_kp.data_ptr(), r_desc.data_ptr(),
                                      r_cnt.data_ptr(), cap, stream.cuda_stream)
@@ -323,7 +333,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": args.workload, "image": [w, h], "nfeatures": nfeat, "levels": levels, "scale": scale,
                        "fast_th": [ini_th, min_th], "frames_per_gpu_per_step": B, "distribution": args.kind,
-                       "inputs": "device-resident", "pyramid_copied_back": False, "blur_variant": "legacy",
+                       "inputs": "device-resident" + (", %d-channel BGR" % args.color if args.color else ""), "pyramid_copied_back": False, "blur_variant": "legacy",
                        "mean_keypoints_per_frame": round(n_out, 1), "sharding": "frames, no collective",
                        **({"stereo": True, "mean_matches_per_pair": round(float(d_nm.float().mean().item()), 1)} if args.stereo else {})},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -203,6 +203,12 @@ class ORBextractor:
         self._check(lib().orbhip_extract_batch_device(self._h, d_imgs, nframes, w, h, row_stride, frame_stride,
                                                       d_kp, d_desc, d_counts, cap, stream))
 
+    def extract_batch_device_color(self, d_imgs, nframes, w, h, row_stride, frame_stride, channels, rgb, d_kp, d_desc, d_counts,
+                                   cap, stream=None):
+        """Raw-pointer batch call on device-resident interleaved colour frames (strides in bytes)."""
+        self._check(lib().orbhip_extract_batch_device_color(self._h, d_imgs, nframes, w, h, row_stride, frame_stride,
+                                                            channels, int(bool(rgb)), d_kp, d_desc, d_counts, cap, stream))
+
     def synchronize(self):
         self._check(lib().orbhip_synchronize(self._h))
 
