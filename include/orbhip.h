@@ -162,6 +162,32 @@ int orbhip_stereo_match(orbhip_extractor* left, orbhip_extractor* right,
                         const orbhip_keypoint* kp_r, const uint8_t* desc_r, int n_r,
                         float mb, float mbf, float* uright, float* depth, int* nmatch);
 
+/* Camera of a Frame: mK (fx, fy, cx, cy) and mDistCoef (k1, k2, p1, p2, k3), the float values
+ * Tracking::Tracking reads from the settings file (src/Tracking.cc:50-75). */
+typedef struct orbhip_camera { float fx, fy, cx, cy, k1, k2, p1, p2, k3; } orbhip_camera;
+
+#define ORBHIP_GRID_COLS 64   /* FRAME_GRID_COLS, include/Frame.h:38 */
+#define ORBHIP_GRID_ROWS 48   /* FRAME_GRID_ROWS, include/Frame.h:37 */
+
+/* Frame::ComputeImageBounds (src/Frame.cc:450-478): bounds = {mnMinX, mnMaxX, mnMinY, mnMaxY} of a
+ * width x height image (the four corners through cv::undistortPoints when k1 != 0). Host only. */
+int orbhip_image_bounds(const orbhip_camera* cam, int width, int height, float bounds[4]);
+
+/* Frame::UndistortKeyPoints (src/Frame.cc:422-449) and Frame::AssignFeaturesToGrid (src/Frame.cc:255-270
+ * with PosInGrid :403-411) for the keypoints of `nframes` frames in device memory (the outputs of
+ * orbhip_extract_batch_device). d_kp_un[nframes][cap] receives mvKeysUn (records with pt replaced;
+ * a copy when k1 == 0, as in the reference). The grid comes back in compressed form: cell
+ * mGrid[x][y] of frame f holds d_grid_idx[f][s .. e) with s = d_grid_start[f][x*48 + y] and
+ * e = d_grid_start[f][x*48 + y + 1] (64*48 + 1 entries per frame), keypoint indices ascending as
+ * the reference pushes them. Enqueued on `stream` (NULL = the handle's own). */
+int orbhip_undistort_grid_batch_device(orbhip_extractor* e, int nframes, const orbhip_keypoint* d_kp,
+                                       const int* d_counts, int cap, const orbhip_camera* cam,
+                                       const float bounds[4], orbhip_keypoint* d_kp_un, int* d_grid_start,
+                                       int* d_grid_idx, void* stream);
+/* The same for one frame with host arrays (n keypoints; grid_start has 64*48 + 1 entries, grid_idx n). */
+int orbhip_undistort_grid(orbhip_extractor* e, const orbhip_keypoint* kp, int n, const orbhip_camera* cam,
+                          const float bounds[4], orbhip_keypoint* kp_un, int* grid_start, int* grid_idx);
+
 const char* orbhip_strerror(int code);
 const char* orbhip_last_error(const orbhip_extractor* e);
 

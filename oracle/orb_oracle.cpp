@@ -902,4 +902,77 @@ void orbo_cvt_gray(const uint8_t* src, int w, int h, size_t sstride, int channel
     }
 }
 
+/* cv::undistortPoints(src, dst, K, distCoeffs, noArray(), K) as the reference calls it
+ * (src/Frame.cc:438, 463): OpenCV's cvUndistortPoints (imgproc/src/undistort.cpp, 2.4 .. 3.x) for
+ * CV_32FC2 points, K and distCoeffs given as CV_32F and widened to double, R = I, P = K, five
+ * iterations. cam = {fx, fy, cx, cy, k1, k2, p1, p2, k3}. */
+void orbo_undistort_points(const float* cam, const float* src_xy, int n, float* dst_xy) {
+    double k[12] = {0};
+    k[0] = cam[4]; k[1] = cam[5]; k[2] = cam[6]; k[3] = cam[7]; k[4] = cam[8];
+    const double fx = cam[0], fy = cam[1], ifx = 1. / fx, ify = 1. / fy, cx = cam[2], cy = cam[3];
+    const double RR[3][3] = {{fx, 0, cx}, {0, fy, cy}, {0, 0, 1}};   /* P * R */
+    for (int i = 0; i < n; i++) {
+        double x = src_xy[2 * i], y = src_xy[2 * i + 1], x0, y0;
+        x0 = x = (x - cx) * ifx;
+        y0 = y = (y - cy) * ify;
+        for (int j = 0; j < 5; j++) {
+            double r2 = x * x + y * y;
+            double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+            double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        double xx = RR[0][0] * x + RR[0][1] * y + RR[0][2];
+        double yy = RR[1][0] * x + RR[1][1] * y + RR[1][2];
+        double ww = 1. / (RR[2][0] * x + RR[2][1] * y + RR[2][2]);
+        dst_xy[2 * i] = (float)(xx * ww);
+        dst_xy[2 * i + 1] = (float)(yy * ww);
+    }
+}
+
+/* Frame::ComputeImageBounds (src/Frame.cc:450-478): bounds = {mnMinX, mnMaxX, mnMinY, mnMaxY}. */
+void orbo_image_bounds(const float* cam, int width, int height, float* bounds) {
+    if (cam[4] != 0.0) {
+        float mat[8] = {0.0f, 0.0f, (float)width, 0.0f, 0.0f, (float)height, (float)width, (float)height};
+        orbo_undistort_points(cam, mat, 4, mat);
+        bounds[0] = std::min(mat[0], mat[4]); bounds[1] = std::max(mat[2], mat[6]);
+        bounds[2] = std::min(mat[1], mat[3]); bounds[3] = std::max(mat[5], mat[7]);
+    } else {
+        bounds[0] = 0.0f; bounds[1] = (float)width; bounds[2] = 0.0f; bounds[3] = (float)height;
+    }
+}
+
+/* Frame::UndistortKeyPoints (src/Frame.cc:422-449) followed by Frame::AssignFeaturesToGrid (:255-270,
+ * PosInGrid :403-411). kp_un receives mvKeysUn; the 64 x 48 lists of mGrid come back concatenated:
+ * cell (x, y) is grid_idx[grid_start[x*48+y] .. grid_start[x*48+y+1]). */
+void orbo_undistort_grid(const float* cam, const float* bounds, const orbo_keypoint* kp, int n,
+                         orbo_keypoint* kp_un, int* grid_start, int* grid_idx) {
+    const int COLS = 64, ROWS = 48;
+    if (cam[4] == 0.0) {
+        for (int i = 0; i < n; i++) kp_un[i] = kp[i];
+    } else {
+        std::vector<float> mat((size_t)2 * std::max(n, 1));
+        for (int i = 0; i < n; i++) { mat[2 * i] = kp[i].x; mat[2 * i + 1] = kp[i].y; }
+        orbo_undistort_points(cam, mat.data(), n, mat.data());
+        for (int i = 0; i < n; i++) { kp_un[i] = kp[i]; kp_un[i].x = mat[2 * i]; kp_un[i].y = mat[2 * i + 1]; }
+    }
+    const float mnMinX = bounds[0], mnMaxX = bounds[1], mnMinY = bounds[2], mnMaxY = bounds[3];
+    const float wInv = static_cast<float>(COLS) / (mnMaxX - mnMinX);      /* src/Frame.cc:128-129 */
+    const float hInv = static_cast<float>(ROWS) / (mnMaxY - mnMinY);
+    std::vector<std::vector<size_t>> grid((size_t)COLS * ROWS);
+    for (int i = 0; i < n; i++) {
+        const int posX = (int)std::round((kp_un[i].x - mnMinX) * wInv);
+        const int posY = (int)std::round((kp_un[i].y - mnMinY) * hInv);
+        if (posX < 0 || posX >= COLS || posY < 0 || posY >= ROWS) continue;
+        grid[(size_t)posX * ROWS + posY].push_back((size_t)i);
+    }
+    int pos = 0;
+    for (int c = 0; c < COLS * ROWS; c++) {
+        grid_start[c] = pos;
+        for (size_t i : grid[c]) grid_idx[pos++] = (int)i;
+    }
+    grid_start[COLS * ROWS] = pos;
+}
+
 } // extern "C"

@@ -101,6 +101,16 @@ double orbo_extract_batch_mt(int nfeatures, float scale_factor, int nlevels, int
 void orbo_cvt_gray(const uint8_t* src, int w, int h, size_t sstride, int channels, int rgb,
                    uint8_t* dst, size_t dstride);
 
+/* cv::undistortPoints with R = I, P = K (src/Frame.cc:438,463); cam = {fx, fy, cx, cy, k1, k2, p1, p2, k3},
+ * points as interleaved x, y floats. */
+void orbo_undistort_points(const float* cam, const float* src_xy, int n, float* dst_xy);
+/* Frame::ComputeImageBounds (src/Frame.cc:450-478): bounds = {mnMinX, mnMaxX, mnMinY, mnMaxY}. */
+void orbo_image_bounds(const float* cam, int width, int height, float* bounds);
+/* Frame::UndistortKeyPoints + Frame::AssignFeaturesToGrid (src/Frame.cc:422-449, 255-270, 403-411);
+ * grid_start has 64*48 + 1 entries, grid_idx up to n. */
+void orbo_undistort_grid(const float* cam, const float* bounds, const orbo_keypoint* kp, int n,
+                         orbo_keypoint* kp_un, int* grid_start, int* grid_idx);
+
 /* Frame::ComputeStereoMatches (reference src/Frame.cc:481-653) on the last extractions of a left and
  * a right instance: kl/dl/nl and kr/dr/nr are their keypoints and descriptors, mb / mbf the stereo
  * baseline (metres) and baseline times fx. uright[nl] / depth[nl] receive mvuRight / mvDepth

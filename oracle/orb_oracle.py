@@ -72,6 +72,9 @@ def lib():
                                             C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, i32p]
         L.orbo_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.orbo_undistort_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orbo_image_bounds.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orbo_undistort_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orbo_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
@@ -169,6 +172,37 @@ def stereo_match(left, right, kp_l, desc_l, kp_r, desc_r, mb, mbf):
     if n < 0:
         raise RuntimeError("orbo_stereo_match failed: %d" % n)
     return uright[:len(kp_l)], depth[:len(kp_l)], n
+
+
+GRID_CELLS = 64 * 48
+
+
+def _cam(cam):
+    return np.ascontiguousarray(cam, np.float32).reshape(9)       # fx, fy, cx, cy, k1, k2, p1, p2, k3
+
+
+def undistort_points(cam, pts):
+    """cv::undistortPoints(pts, pts, K, distCoeffs, noArray(), K) for an (n, 2) float32 array."""
+    pts = np.ascontiguousarray(pts, np.float32)
+    out = np.zeros_like(pts)
+    lib().orbo_undistort_points(_ptr(_cam(cam)), _ptr(pts), len(pts), _ptr(out))
+    return out
+
+
+def image_bounds(cam, width, height):
+    out = np.zeros(4, np.float32)
+    lib().orbo_image_bounds(_ptr(_cam(cam)), width, height, _ptr(out))
+    return out
+
+
+def undistort_grid(cam, bounds, kp):
+    """Frame::UndistortKeyPoints + Frame::AssignFeaturesToGrid: returns (mvKeysUn, grid_start, grid_idx)."""
+    kp = np.ascontiguousarray(kp, KP_DTYPE)
+    un = np.zeros(max(len(kp), 1), KP_DTYPE)
+    gs = np.zeros(GRID_CELLS + 1, np.int32)
+    gi = np.zeros(max(len(kp), 1), np.int32)
+    lib().orbo_undistort_grid(_ptr(_cam(cam)), _ptr(np.ascontiguousarray(bounds, np.float32)), _ptr(kp), len(kp), _ptr(un), _ptr(gs), _ptr(gi))
+    return un[:len(kp)], gs, gi[:gs[-1]]
 
 
 def cvt_gray(img, rgb):

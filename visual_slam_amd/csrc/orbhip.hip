@@ -17,6 +17,7 @@
 #include "orb_device.h"
 #include "orb_kernels.h"
 #include "orb_stereo.h"
+#include "orb_grid.h"
 
 namespace {
 
@@ -852,6 +853,72 @@ int orbhip_stereo_match(orbhip_extractor* left, orbhip_extractor* right,
     HIP_TRY(e, hipMemcpy(uright, d_u, (size_t)n_l * sizeof(float), hipMemcpyDeviceToHost));
     HIP_TRY(e, hipMemcpy(depth, d_d, (size_t)n_l * sizeof(float), hipMemcpyDeviceToHost));
     if (nmatch) HIP_TRY(e, hipMemcpy(nmatch, d_cnt + 2, sizeof(int), hipMemcpyDeviceToHost));
+    return ORBHIP_OK;
+}
+
+int orbhip_image_bounds(const orbhip_camera* cam, int width, int height, float bounds[4]) {
+    if (!cam || !bounds || width < 1 || height < 1) return ORBHIP_ERR_ARG;
+    if (cam->k1 != 0.0f) {                                     // src/Frame.cc:453-470
+        const CamDev c = {cam->fx, cam->fy, cam->cx, cam->cy, cam->k1, cam->k2, cam->p1, cam->p2, cam->k3};
+        float x[4] = {0.0f, (float)width, 0.0f, (float)width}, y[4] = {0.0f, 0.0f, (float)height, (float)height};
+        for (int i = 0; i < 4; i++) undistort_point(c, x[i], y[i]);
+        bounds[0] = std::min(x[0], x[2]); bounds[1] = std::max(x[1], x[3]);
+        bounds[2] = std::min(y[0], y[1]); bounds[3] = std::max(y[2], y[3]);
+    } else {                                                   // src/Frame.cc:471-477
+        bounds[0] = 0.0f; bounds[1] = (float)width; bounds[2] = 0.0f; bounds[3] = (float)height;
+    }
+    return ORBHIP_OK;
+}
+
+int orbhip_undistort_grid_batch_device(orbhip_extractor* e, int nframes, const orbhip_keypoint* d_kp,
+                                       const int* d_counts, int cap, const orbhip_camera* cam,
+                                       const float bounds[4], orbhip_keypoint* d_kp_un, int* d_grid_start,
+                                       int* d_grid_idx, void* stream) {
+    if (!e || nframes < 1 || !d_kp || !d_counts || cap < 1 || !cam || !bounds || !d_kp_un || !d_grid_start || !d_grid_idx ||
+        !(bounds[1] > bounds[0]) || !(bounds[3] > bounds[2]))
+        return ORBHIP_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    const CamDev c = {cam->fx, cam->fy, cam->cx, cam->cy, cam->k1, cam->k2, cam->p1, cam->p2, cam->k3};
+    // mfGridElementWidthInv / mfGridElementHeightInv (src/Frame.cc:128-129)
+    const float inv_w = static_cast<float>(GRID_COLS) / (bounds[1] - bounds[0]);
+    const float inv_h = static_cast<float>(GRID_ROWS) / (bounds[3] - bounds[2]);
+    hipLaunchKernelGGL(k_undistort_grid, dim3(nframes), dim3(256), 0, s, reinterpret_cast<const GridKp*>(d_kp), d_counts, cap, c,
+                       bounds[0], bounds[2], inv_w, inv_h, reinterpret_cast<GridKp*>(d_kp_un), d_grid_start, d_grid_idx);
+    HIP_TRY(e, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_undistort_grid(orbhip_extractor* e, const orbhip_keypoint* kp, int n, const orbhip_camera* cam,
+                          const float bounds[4], orbhip_keypoint* kp_un, int* grid_start, int* grid_idx) {
+    if (!e || n < 0 || !cam || !bounds || !grid_start || (n > 0 && (!kp || !kp_un || !grid_idx))) return ORBHIP_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    const int cap = std::max(n, 1);
+    const size_t kpb = (size_t)cap * sizeof(orbhip_keypoint), gsb = (size_t)(GRID_CELLS + 1) * sizeof(int), gib = (size_t)cap * sizeof(int);
+    const size_t need = 64 + 2 * kpb + gsb + gib;
+    if (need > e->d_st_tmp_bytes) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        dfree(e->d_st_tmp);
+        HIP_TRY(e, hipMalloc(&e->d_st_tmp, need));
+        e->d_st_tmp_bytes = need;
+    }
+    uint8_t* p = e->d_st_tmp;
+    int* d_cnt = reinterpret_cast<int*>(p); p += 64;
+    orbhip_keypoint* d_k = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
+    orbhip_keypoint* d_u = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
+    int* d_gs = reinterpret_cast<int*>(p); p += gsb;
+    int* d_gi = reinterpret_cast<int*>(p);
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(d_cnt, &n, sizeof(int), hipMemcpyHostToDevice));
+    if (n > 0) HIP_TRY(e, hipMemcpy(d_k, kp, (size_t)n * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
+    int rc = orbhip_undistort_grid_batch_device(e, 1, d_k, d_cnt, cap, cam, bounds, d_u, d_gs, d_gi, nullptr);
+    if (rc) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (n > 0) {
+        HIP_TRY(e, hipMemcpy(kp_un, d_u, (size_t)n * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost));
+        HIP_TRY(e, hipMemcpy(grid_idx, d_gi, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    HIP_TRY(e, hipMemcpy(grid_start, d_gs, gsb, hipMemcpyDeviceToHost));
     return ORBHIP_OK;
 }
 

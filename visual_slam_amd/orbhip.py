@@ -32,6 +32,7 @@ EXPORTS = [
     "orbhip_debug_candidates", "orbhip_enable_timing", "orbhip_get_timing", "orbhip_strerror",
     "orbhip_last_error", "orbhip_stereo_match", "orbhip_stereo_match_batch_device",
     "orbhip_extract_color", "orbhip_extract_batch_device_color",
+    "orbhip_image_bounds", "orbhip_undistort_grid", "orbhip_undistort_grid_batch_device",
 ]
 
 
@@ -87,6 +88,9 @@ def lib():
         L.orbhip_extract_color.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, vp, C.c_int, ip, vp]
         L.orbhip_extract_batch_device_color.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
                                                         vp, vp, vp, C.c_int, vp]
+        L.orbhip_image_bounds.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.orbhip_undistort_grid.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp]
+        L.orbhip_undistort_grid_batch_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
         L.orbhip_stereo_match.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, ip]
         L.orbhip_stereo_match_batch_device.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float,
                                                        vp, vp, vp, vp]
@@ -96,6 +100,35 @@ def lib():
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+GRID_CELLS = 64 * 48          # FRAME_GRID_COLS x FRAME_GRID_ROWS (include/Frame.h:37-38)
+
+
+def _cam(cam):
+    return np.ascontiguousarray(cam, np.float32).reshape(9)       # fx, fy, cx, cy, k1, k2, p1, p2, k3
+
+
+def ComputeImageBounds(cam, width, height):
+    """Frame::ComputeImageBounds (reference src/Frame.cc:450-478): mnMinX, mnMaxX, mnMinY, mnMaxY."""
+    out = np.zeros(4, np.float32)
+    rc = lib().orbhip_image_bounds(_ptr(_cam(cam)), width, height, _ptr(out))
+    if rc:
+        raise OrbHipError(rc)
+    return out
+
+
+def UndistortAndAssignToGrid(ex, kp, cam, bounds):
+    """Frame::UndistortKeyPoints + Frame::AssignFeaturesToGrid (reference src/Frame.cc:422-449, 255-270)
+    on the device: returns (mvKeysUn, grid_start[64*48+1], grid_idx)."""
+    kp = np.ascontiguousarray(kp, KP_DTYPE)
+    n = len(kp)
+    un = np.zeros(max(n, 1), KP_DTYPE)
+    gs = np.zeros(GRID_CELLS + 1, np.int32)
+    gi = np.zeros(max(n, 1), np.int32)
+    ex._check(lib().orbhip_undistort_grid(ex._h, _ptr(kp), n, _ptr(_cam(cam)), _ptr(np.ascontiguousarray(bounds, np.float32)),
+                                          _ptr(un), _ptr(gs), _ptr(gi)))
+    return un[:n], gs, gi[:gs[-1]]
 
 
 def ComputeStereoMatches(left, right, kp_l, desc_l, kp_r, desc_r, mb, mbf):
