@@ -48,3 +48,36 @@ def test_two_instances_on_two_threads_like_stereo():
         assert np.mean(np.all(desc == odesc, axis=1)) >= 0.999
         for l in range(8):   # each instance keeps its own pyramid (ComputeStereoMatches reads both)
             assert np.array_equal(ex.mvImagePyramid[l], o.level(l)), (name, l)
+
+
+@pytest.mark.gpu
+def test_two_passes_in_flight_give_the_same_results():
+    """ORBHIP_LANES=2 splits a large batch into passes on two internal streams (read at handle
+    creation, so it runs in a child process); the outputs must equal the single-stream ones."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from visual_slam_amd import orbhip, synth\n"
+        "imgs = synth.batch('blocks', 320, 240, 80)\n"
+        "ex = orbhip.ORBextractor(300, 1.2, 6, 20, 7, max_batch=64)\n"
+        "res = ex.extract_batch(imgs)\n"
+        "np.savez(sys.argv[1], n=np.array([len(k) for k, d in res]), kp=np.concatenate([k for k, d in res]),\n"
+        "         desc=np.concatenate([d for k, d in res]))\n"
+    ) % str(root)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for lanes in ("1", "2"):
+            path = os.path.join(tmp, "lanes%s.npz" % lanes)
+            env = dict(os.environ, ORBHIP_LANES=lanes)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=240)
+            with np.load(path) as z:
+                out[lanes] = {k: z[k] for k in z.files}
+    assert out["1"]["n"].sum() > 80 * 100
+    for k in ("n", "kp", "desc"):
+        assert np.array_equal(out["1"][k], out["2"][k]), k
