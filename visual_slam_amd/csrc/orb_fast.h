@@ -20,15 +20,20 @@
 //                     coalesced dword loads in flight per lane, neighbour dwords by DPP wave
 //                     shifts), the step is fully unrolled. Straight
 //                     edges fail this test; the survivors of a step are compacted into a
-//                     per-wave queue with one wave prefix sum. The loaded rows are also copied
-//                     into an image tile in LDS.
-//   score  (sparse) : queued pixels are taken 64 at a time, one per lane: 16 ring bytes from
-//                     the LDS image tile, exact score, written to a byte map of the tile in LDS.
-//   nms    (sparse) : after a barrier every wave scans its 8 map rows, compacts the non-zero
-//                     scores the same way and handles them one per lane: non-maximum suppression
-//                     inside the cell, then a plain store into the wave's own output segment
+//                     per-wave queue with one wave prefix sum (raw codes, decoded where they
+//                     are consumed). The loaded rows are also copied into an image tile in LDS.
+//   score  (sparse) : queued pixels are taken 64 at a time, one per lane (a remainder waits
+//                     for the next step): 16 ring bytes from the LDS image tile, exact score,
+//                     written to a byte map of the tile in LDS, plus one bit per scored pixel
+//                     in an occupancy map.
+//   nms    (sparse) : after a barrier every wave reads the occupancy bits of its 8 map rows,
+//                     compacts the scored pixels the same way and handles them one per lane:
+//                     non-maximum suppression inside the cell (all eight neighbour reads in
+//                     flight), then a plain store into the wave's own output segment
 //                     (no atomics, no ordering between waves: the consumer does not depend on
 //                     the order of the candidates).
+// Row bookkeeping is wave-uniform and runs on the scalar unit; tiles are taken in an XCD-aware
+// order so that the rows and cache lines neighbouring tiles share are fetched from memory once.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "orb_device.h"
