@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const PlanDev* __restrict_
                                                       const StKp* __restrict__ kp_l, const uint8_t* __restrict__ desc_l,
                                                       const int* __restrict__ cnt_l,
                                                       const StKp* __restrict__ kp_r, const uint8_t* __restrict__ desc_r,
-                                                      const int* __restrict__ cnt_r, int cap, float mb, float mbf,
+                                                      int cap, float mb, float mbf,
                                                       float* __restrict__ uright, float* __restrict__ depth,
                                                       int* __restrict__ sad_out) {
     __shared__ int s_dist[4][12];
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const PlanDev* __restrict_
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int f = blockIdx.y;
     const int iL = blockIdx.x * 4 + wv;
-    const int nl = min(cnt_l[f], cap), nr = min(cnt_r[f], cap);
+    const int nl = min(cnt_l[f], cap);
     if (iL >= nl) return;                                      // waves are independent: no workgroup barrier below
     const size_t o = (size_t)f * cap;
     const StKp kL = kp_l[o + iL];
