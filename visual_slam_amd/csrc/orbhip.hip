@@ -684,8 +684,20 @@ int orbhip_pyramid_copy(orbhip_extractor* e, int frame, int level, uint8_t* dst,
     if (dst_stride < (size_t)(g.w + 2 * b)) return ORBHIP_ERR_ARG;
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipDeviceSynchronize());
-    const uint8_t* src = e->ws[e->last_ws].d_pyr + g.pyr_off + (size_t)frame * g.plane_bytes + (size_t)(ORB_OY - b) * g.pitch + (ORB_OX - b);
-    HIP_TRY(e, hipMemcpy2D(dst, dst_stride, src, g.pitch, g.w + 2 * b, g.h + 2 * b, hipMemcpyDeviceToHost));
+    // the rows of the plane are contiguous in device memory: one copy into pinned memory, then the
+    // rows are cut out on the host (a 2-D copy into pageable memory would go row by row)
+    const int rows = g.h + 2 * b;
+    const size_t bytes = (size_t)rows * g.pitch;
+    if (bytes > e->h_out_bytes) {
+        if (e->h_out) (void)hipHostFree(e->h_out);
+        e->h_out = nullptr; e->h_out_bytes = 0;
+        HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_out), bytes, hipHostMallocDefault));
+        e->h_out_bytes = bytes;
+    }
+    const uint8_t* src = e->ws[e->last_ws].d_pyr + g.pyr_off + (size_t)frame * g.plane_bytes + (size_t)(ORB_OY - b) * g.pitch;
+    HIP_TRY(e, hipMemcpy(e->h_out, src, bytes, hipMemcpyDeviceToHost));
+    for (int y = 0; y < rows; y++)
+        std::memcpy(dst + (size_t)y * dst_stride, e->h_out + (size_t)y * g.pitch + (ORB_OX - b), (size_t)(g.w + 2 * b));
     return ORBHIP_OK;
 }
 
