@@ -290,7 +290,7 @@ def main():
                                               "kernel_ms_per_step": {k: round(v[0] / 2, 3) for k, v in t1.items()}}
             del ex1
         cpu = None
-        if args.cpu_frames > 0:
+        if args.cpu_frames > 0 and world == 1:           # the CPU baseline is timed at N = 1 only
             from oracle import orb_oracle   # checker / baseline only, never on the measured GPU path
             from visual_slam_amd import synth
             nthreads = min(16, os.cpu_count() or 1)
