@@ -188,6 +188,26 @@ int orbhip_undistort_grid_batch_device(orbhip_extractor* e, int nframes, const o
 int orbhip_undistort_grid(orbhip_extractor* e, const orbhip_keypoint* kp, int n, const orbhip_camera* cam,
                           const float bounds[4], orbhip_keypoint* kp_un, int* grid_start, int* grid_idx);
 
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)
+ * (src/ORBmatcher.cc:402-517; called with ORBmatcher(0.9, true) and windowSize 100 at
+ * src/Tracking.cc:588-589) for `nframes` frame pairs in device memory. d_kp_un1 / d_kp_un2 are the
+ * undistorted keypoints of the initial and of the current frames (mvKeysUn, e.g. from
+ * orbhip_undistort_grid_batch_device), d_desc* / d_cnt* their descriptors and counts, bounds the
+ * image bounds of the frames' grid (orbhip_image_bounds). d_prev_matched[nframes][cap][2] holds
+ * vbPrevMatched (x, y per F1 keypoint) and is updated as the reference updates it;
+ * d_matches12[nframes][cap] receives vnMatches12 (-1 = none), d_nmatches[nframes] the return value. */
+int orbhip_search_for_initialization_batch_device(orbhip_extractor* e, int nframes,
+                                                  const orbhip_keypoint* d_kp_un1, const uint8_t* d_desc1, const int* d_cnt1,
+                                                  const orbhip_keypoint* d_kp_un2, const uint8_t* d_desc2, const int* d_cnt2,
+                                                  int cap, const float bounds[4], float* d_prev_matched, int window_size,
+                                                  float nnratio, int check_orientation, int* d_matches12, int* d_nmatches,
+                                                  void* stream);
+/* The same for one pair with host arrays; prev_matched has n1 (x, y) pairs, matches12 n1 ints. */
+int orbhip_search_for_initialization(orbhip_extractor* e, const orbhip_keypoint* kp_un1, const uint8_t* desc1, int n1,
+                                     const orbhip_keypoint* kp_un2, const uint8_t* desc2, int n2, const float bounds[4],
+                                     float* prev_matched, int window_size, float nnratio, int check_orientation,
+                                     int* matches12, int* nmatches);
+
 const char* orbhip_strerror(int code);
 const char* orbhip_last_error(const orbhip_extractor* e);
 

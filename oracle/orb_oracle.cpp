@@ -975,4 +975,121 @@ void orbo_undistort_grid(const float* cam, const float* bounds, const orbo_keypo
     grid_start[COLS * ROWS] = pos;
 }
 
+/* ORBmatcher::SearchForInitialization (reference src/ORBmatcher.cc:402-517) with
+ * Frame::GetFeaturesInArea (src/Frame.cc:351-401), Frame::AssignFeaturesToGrid / PosInGrid for F2's
+ * grid (src/Frame.cc:255-270, 403-411), ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1611-1627)
+ * and ComputeThreeMaxima (src/ORBmatcher.cc:1566-1607). k1 / k2 are mvKeysUn of F1 / F2, bounds =
+ * {mnMinX, mnMaxX, mnMinY, mnMaxY}; prev_matched (n1 x/y pairs) is vbPrevMatched, updated in place;
+ * matches12 receives vnMatches12. Returns nmatches. */
+int orbo_search_for_initialization(const orbo_keypoint* k1, const uint8_t* d1, int n1,
+                                   const orbo_keypoint* k2, const uint8_t* d2, int n2, const float* bounds,
+                                   float* prev_matched, int windowSize, float mfNNratio, int mbCheckOrientation,
+                                   int* matches12) {
+    const int COLS = 64, ROWS = 48, HISTO_LENGTH = 30, TH_LOW = 50;
+    const float mnMinX = bounds[0], mnMaxX = bounds[1], mnMinY = bounds[2], mnMaxY = bounds[3];
+    const float wInv = static_cast<float>(COLS) / (mnMaxX - mnMinX);
+    const float hInv = static_cast<float>(ROWS) / (mnMaxY - mnMinY);
+    /* F2.mGrid */
+    std::vector<std::vector<size_t>> mGrid((size_t)COLS * ROWS);
+    for (int i = 0; i < n2; i++) {
+        const int posX = (int)std::round((k2[i].x - mnMinX) * wInv);
+        const int posY = (int)std::round((k2[i].y - mnMinY) * hInv);
+        if (posX < 0 || posX >= COLS || posY < 0 || posY >= ROWS) continue;
+        mGrid[(size_t)posX * ROWS + posY].push_back((size_t)i);
+    }
+    auto GetFeaturesInArea = [&](float x, float y, float r, int minLevel, int maxLevel) {
+        std::vector<size_t> vIndices;
+        const int nMinCellX = std::max(0, (int)std::floor((x - mnMinX - r) * wInv));
+        if (nMinCellX >= COLS) return vIndices;
+        const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((x - mnMinX + r) * wInv));
+        if (nMaxCellX < 0) return vIndices;
+        const int nMinCellY = std::max(0, (int)std::floor((y - mnMinY - r) * hInv));
+        if (nMinCellY >= ROWS) return vIndices;
+        const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((y - mnMinY + r) * hInv));
+        if (nMaxCellY < 0) return vIndices;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                const std::vector<size_t>& vCell = mGrid[(size_t)ix * ROWS + iy];
+                for (size_t j = 0; j < vCell.size(); j++) {
+                    const orbo_keypoint& kpUn = k2[vCell[j]];
+                    if (bCheckLevels) {
+                        if (kpUn.octave < minLevel) continue;
+                        if (maxLevel >= 0 && kpUn.octave > maxLevel) continue;
+                    }
+                    const float distx = kpUn.x - x, disty = kpUn.y - y;
+                    if (std::fabs(distx) < r && std::fabs(disty) < r) vIndices.push_back(vCell[j]);
+                }
+            }
+        return vIndices;
+    };
+    auto DescriptorDistance = [](const uint8_t* a, const uint8_t* b) {
+        int dist = 0;
+        for (int i = 0; i < 8; i++) {
+            uint32_t pa, pb;
+            std::memcpy(&pa, a + 4 * i, 4); std::memcpy(&pb, b + 4 * i, 4);
+            unsigned int v = pa ^ pb;
+            v = v - ((v >> 1) & 0x55555555);
+            v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+            dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+        }
+        return dist;
+    };
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> vMatchedDistance((size_t)n2, 2147483647), vnMatches21((size_t)n2, -1);
+    for (int i1 = 0; i1 < n1; i1++) {
+        const orbo_keypoint kp1 = k1[i1];
+        const int level1 = kp1.octave;
+        if (level1 > 0) continue;
+        std::vector<size_t> vIndices2 = GetFeaturesInArea(prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)windowSize, level1, level1);
+        if (vIndices2.empty()) continue;
+        int bestDist = 2147483647, bestDist2 = 2147483647, bestIdx2 = -1;
+        for (size_t i2 : vIndices2) {
+            const int dist = DescriptorDistance(d1 + (size_t)i1 * 32, d2 + i2 * 32);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = (int)i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * mfNNratio) {
+                if (vnMatches21[bestIdx2] >= 0) { matches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+                matches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (mbCheckOrientation) {
+                    float rot = k1[i1].angle - k2[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        int max1 = 0, max2 = 0, max3 = 0;                      /* ComputeThreeMaxima */
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int sz = (int)rotHist[i].size();
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i])
+                if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)
+        if (matches12[i1] >= 0) { prev_matched[2 * i1] = k2[matches12[i1]].x; prev_matched[2 * i1 + 1] = k2[matches12[i1]].y; }
+    return nmatches;
+}
+
 } // extern "C"

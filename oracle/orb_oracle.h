@@ -111,6 +111,14 @@ void orbo_image_bounds(const float* cam, int width, int height, float* bounds);
 void orbo_undistort_grid(const float* cam, const float* bounds, const orbo_keypoint* kp, int n,
                          orbo_keypoint* kp_un, int* grid_start, int* grid_idx);
 
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:402-517) on the undistorted keypoints and
+ * descriptors of an initial (1) and a current (2) frame; prev_matched = vbPrevMatched (in/out),
+ * matches12 = vnMatches12 (out). Returns nmatches. */
+int orbo_search_for_initialization(const orbo_keypoint* k1, const uint8_t* d1, int n1,
+                                   const orbo_keypoint* k2, const uint8_t* d2, int n2, const float* bounds,
+                                   float* prev_matched, int windowSize, float mfNNratio, int mbCheckOrientation,
+                                   int* matches12);
+
 /* Frame::ComputeStereoMatches (reference src/Frame.cc:481-653) on the last extractions of a left and
  * a right instance: kl/dl/nl and kr/dr/nr are their keypoints and descriptors, mb / mbf the stereo
  * baseline (metres) and baseline times fx. uright[nl] / depth[nl] receive mvuRight / mvDepth

@@ -75,6 +75,8 @@ def lib():
         L.orbo_undistort_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orbo_image_bounds.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orbo_undistort_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orbo_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                     C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.orbo_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
@@ -203,6 +205,18 @@ def undistort_grid(cam, bounds, kp):
     gi = np.zeros(max(len(kp), 1), np.int32)
     lib().orbo_undistort_grid(_ptr(_cam(cam)), _ptr(np.ascontiguousarray(bounds, np.float32)), _ptr(kp), len(kp), _ptr(un), _ptr(gs), _ptr(gi))
     return un[:len(kp)], gs, gi[:gs[-1]]
+
+
+def search_for_initialization(kp1, desc1, kp2, desc2, bounds, prev_matched, window=100, nnratio=0.9, check_orientation=True):
+    """ORBmatcher::SearchForInitialization: returns (vnMatches12, updated vbPrevMatched, nmatches)."""
+    kp1 = np.ascontiguousarray(kp1, KP_DTYPE); kp2 = np.ascontiguousarray(kp2, KP_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    prev = np.array(prev_matched, np.float32).reshape(-1, 2).copy()
+    m12 = np.full(max(len(kp1), 1), -1, np.int32)
+    n = lib().orbo_search_for_initialization(_ptr(kp1), _ptr(desc1), len(kp1), _ptr(kp2), _ptr(desc2), len(kp2),
+                                             _ptr(np.ascontiguousarray(bounds, np.float32)), _ptr(prev), int(window),
+                                             float(nnratio), int(bool(check_orientation)), _ptr(m12))
+    return m12[:len(kp1)], prev, n
 
 
 def cvt_gray(img, rgb):

@@ -18,6 +18,7 @@
 #include "orb_kernels.h"
 #include "orb_stereo.h"
 #include "orb_grid.h"
+#include "orb_match.h"
 
 namespace {
 
@@ -931,6 +932,77 @@ int orbhip_undistort_grid(orbhip_extractor* e, const orbhip_keypoint* kp, int n,
         HIP_TRY(e, hipMemcpy(grid_idx, d_gi, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     }
     HIP_TRY(e, hipMemcpy(grid_start, d_gs, gsb, hipMemcpyDeviceToHost));
+    return ORBHIP_OK;
+}
+
+int orbhip_search_for_initialization_batch_device(orbhip_extractor* e, int nframes,
+                                                  const orbhip_keypoint* d_kp_un1, const uint8_t* d_desc1, const int* d_cnt1,
+                                                  const orbhip_keypoint* d_kp_un2, const uint8_t* d_desc2, const int* d_cnt2,
+                                                  int cap, const float bounds[4], float* d_prev_matched, int window_size,
+                                                  float nnratio, int check_orientation, int* d_matches12, int* d_nmatches,
+                                                  void* stream) {
+    if (!e || nframes < 1 || !d_kp_un1 || !d_desc1 || !d_cnt1 || !d_kp_un2 || !d_desc2 || !d_cnt2 || cap < 1 || cap > 65534 ||
+        !bounds || !(bounds[1] > bounds[0]) || !(bounds[3] > bounds[2]) || !d_prev_matched || !d_matches12 || !d_nmatches)
+        return ORBHIP_ERR_ARG;
+    const size_t lds = (size_t)MT_LDS_PER_KP * cap + 16;
+    if (lds > 160 * 1024 - 512) { e->err = "too many keypoints per frame for the on-chip matcher state"; return ORBHIP_ERR_CAPACITY; }
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    if (lds > 64 * 1024)
+        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_init), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const float inv_w = static_cast<float>(GRID_COLS) / (bounds[1] - bounds[0]);
+    const float inv_h = static_cast<float>(GRID_ROWS) / (bounds[3] - bounds[2]);
+    hipLaunchKernelGGL(k_search_init, dim3(nframes), dim3(64), lds, s,
+                       reinterpret_cast<const GridKp*>(d_kp_un1), d_desc1, d_cnt1, reinterpret_cast<const GridKp*>(d_kp_un2), d_desc2,
+                       d_cnt2, cap, bounds[0], bounds[2], inv_w, inv_h, (float)window_size, nnratio, check_orientation,
+                       reinterpret_cast<float2*>(d_prev_matched), d_matches12, d_nmatches);
+    HIP_TRY(e, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_search_for_initialization(orbhip_extractor* e, const orbhip_keypoint* kp_un1, const uint8_t* desc1, int n1,
+                                     const orbhip_keypoint* kp_un2, const uint8_t* desc2, int n2, const float bounds[4],
+                                     float* prev_matched, int window_size, float nnratio, int check_orientation,
+                                     int* matches12, int* nmatches) {
+    if (!e || n1 < 0 || n2 < 0 || !bounds || !nmatches) return ORBHIP_ERR_ARG;
+    if (n1 == 0) { *nmatches = 0; return ORBHIP_OK; }
+    if (!kp_un1 || !desc1 || !prev_matched || !matches12 || (n2 > 0 && (!kp_un2 || !desc2))) return ORBHIP_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    const int cap = std::max(std::max(n1, n2), 1);
+    const size_t kpb = (size_t)cap * sizeof(orbhip_keypoint), db = (size_t)cap * 32;
+    const size_t pb = (size_t)cap * 2 * sizeof(float), mb = (size_t)cap * sizeof(int);
+    const size_t need = 64 + 2 * kpb + 2 * db + pb + mb;
+    if (need > e->d_st_tmp_bytes) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        dfree(e->d_st_tmp);
+        HIP_TRY(e, hipMalloc(&e->d_st_tmp, need));
+        e->d_st_tmp_bytes = need;
+    }
+    uint8_t* p = e->d_st_tmp;
+    int* d_cnt = reinterpret_cast<int*>(p); p += 64;            // [0] n1, [1] n2, [2] matches
+    orbhip_keypoint* d_k1 = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
+    orbhip_keypoint* d_k2 = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
+    uint8_t* d_d1 = p; p += db;
+    uint8_t* d_d2 = p; p += db;
+    float* d_prev = reinterpret_cast<float*>(p); p += pb;
+    int* d_m12 = reinterpret_cast<int*>(p);
+    const int cnt[3] = {n1, n2, 0};
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(d_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_k1, kp_un1, (size_t)n1 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_d1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_prev, prev_matched, (size_t)n1 * 2 * sizeof(float), hipMemcpyHostToDevice));
+    if (n2 > 0) {
+        HIP_TRY(e, hipMemcpy(d_k2, kp_un2, (size_t)n2 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(d_d2, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
+    }
+    int rc = orbhip_search_for_initialization_batch_device(e, 1, d_k1, d_d1, d_cnt, d_k2, d_d2, d_cnt + 1, cap, bounds, d_prev,
+                                                           window_size, nnratio, check_orientation, d_m12, d_cnt + 2, nullptr);
+    if (rc) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(prev_matched, d_prev, (size_t)n1 * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(matches12, d_m12, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(nmatches, d_cnt + 2, sizeof(int), hipMemcpyDeviceToHost));
     return ORBHIP_OK;
 }
 

@@ -33,6 +33,7 @@ EXPORTS = [
     "orbhip_last_error", "orbhip_stereo_match", "orbhip_stereo_match_batch_device",
     "orbhip_extract_color", "orbhip_extract_batch_device_color",
     "orbhip_image_bounds", "orbhip_undistort_grid", "orbhip_undistort_grid_batch_device",
+    "orbhip_search_for_initialization", "orbhip_search_for_initialization_batch_device",
 ]
 
 
@@ -91,6 +92,9 @@ def lib():
         L.orbhip_image_bounds.argtypes = [vp, C.c_int, C.c_int, vp]
         L.orbhip_undistort_grid.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp]
         L.orbhip_undistort_grid_batch_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
+        L.orbhip_search_for_initialization.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_int, vp, ip]
+        L.orbhip_search_for_initialization_batch_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int,
+                                                                    C.c_float, C.c_int, vp, vp, vp]
         L.orbhip_stereo_match.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, ip]
         L.orbhip_stereo_match_batch_device.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float,
                                                        vp, vp, vp, vp]
@@ -129,6 +133,20 @@ def UndistortAndAssignToGrid(ex, kp, cam, bounds):
     ex._check(lib().orbhip_undistort_grid(ex._h, _ptr(kp), n, _ptr(_cam(cam)), _ptr(np.ascontiguousarray(bounds, np.float32)),
                                           _ptr(un), _ptr(gs), _ptr(gi)))
     return un[:n], gs, gi[:gs[-1]]
+
+
+def SearchForInitialization(ex, kp1, desc1, kp2, desc2, bounds, prev_matched, window=100, nnratio=0.9, check_orientation=True):
+    """ORBmatcher::SearchForInitialization (reference src/ORBmatcher.cc:402-517) on the device: returns
+    (vnMatches12, updated vbPrevMatched, nmatches)."""
+    kp1 = np.ascontiguousarray(kp1, KP_DTYPE); kp2 = np.ascontiguousarray(kp2, KP_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    prev = np.array(prev_matched, np.float32).reshape(-1, 2).copy()
+    m12 = np.full(max(len(kp1), 1), -1, np.int32)
+    n = C.c_int(0)
+    ex._check(lib().orbhip_search_for_initialization(ex._h, _ptr(kp1), _ptr(desc1), len(kp1), _ptr(kp2), _ptr(desc2), len(kp2),
+                                                     _ptr(np.ascontiguousarray(bounds, np.float32)), _ptr(prev), int(window),
+                                                     float(nnratio), int(bool(check_orientation)), _ptr(m12), C.byref(n)))
+    return m12[:len(kp1)], prev, n.value
 
 
 def ComputeStereoMatches(left, right, kp_l, desc_l, kp_r, desc_r, mb, mbf):
