@@ -32,8 +32,9 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 
 // Grid (frames), one wave per workgroup. Dynamic LDS per F2 keypoint: position (8 bytes), grid cell
 // or -1 when it can never be a candidate (2), the distance and the F1 index that currently hold it
-// (2 + 2); per F1 keypoint the rotation bin it was matched in (1): MT_LDS_PER_KP bytes in all.
-#define MT_LDS_PER_KP 15
+// (2 + 2), a slot of the compact list of eligible F2 keypoints (2); per F1 keypoint the rotation bin
+// it was matched in (1): MT_LDS_PER_KP bytes in all.
+#define MT_LDS_PER_KP 17
 __global__ __launch_bounds__(64) void k_search_init(const GridKp* __restrict__ kp1, const uint8_t* __restrict__ desc1,
                                                     const int* __restrict__ cnt1, const GridKp* __restrict__ kp2,
                                                     const uint8_t* __restrict__ desc2, const int* __restrict__ cnt2, int cap,
@@ -45,7 +46,8 @@ __global__ __launch_bounds__(64) void k_search_init(const GridKp* __restrict__ k
     int16_t* cell2 = reinterpret_cast<int16_t*>(mt_smem + 8 * (size_t)cap);   // its grid cell; -1: outside the grid or octave > 0
     uint16_t* matched_dist = reinterpret_cast<uint16_t*>(cell2 + cap);   // vMatchedDistance (0xFFFF = INT_MAX)
     uint16_t* matches21 = matched_dist + cap;                 // vnMatches21 (0xFFFF = -1)
-    uint8_t* bin_of = reinterpret_cast<uint8_t*>(matches21 + cap);   // rotation bin of i1 when it was matched, 0xFF = none
+    uint16_t* elig = matches21 + cap;                         // indices of the F2 keypoints that can be candidates at all
+    uint8_t* bin_of = reinterpret_cast<uint8_t*>(elig + cap);   // rotation bin of i1 when it was matched, 0xFF = none
     __shared__ int s_hist[MT_HISTO];
     const int lane = threadIdx.x, f = blockIdx.x;
     const size_t o = (size_t)f * cap;
@@ -54,13 +56,22 @@ __global__ __launch_bounds__(64) void k_search_init(const GridKp* __restrict__ k
     const GridKp* K2 = kp2 + o;
     int* m12 = matches12 + o;
     float2* prev = prev_matched + o;
-    for (int i = lane; i < n2; i += 64) {
-        const GridKp k2 = K2[i];
-        const int cell = grid_cell(k2.x, k2.y, min_x, min_y, inv_w, inv_h);
-        pos2[i] = make_float2(k2.x, k2.y);
-        cell2[i] = (int16_t)((cell < 0 || k2.octave != 0) ? -1 : cell);   // minLevel = maxLevel = 0
-        matched_dist[i] = 0xFFFF;
-        matches21[i] = 0xFFFF;
+    int nelig = 0;
+    for (int i0 = 0; i0 < n2; i0 += 64) {                      // wave-uniform trip count
+        const int i = i0 + lane;
+        bool ok = false;
+        if (i < n2) {
+            const GridKp k2 = K2[i];
+            const int cell = grid_cell(k2.x, k2.y, min_x, min_y, inv_w, inv_h);
+            ok = cell >= 0 && k2.octave == 0;                  // in the grid; minLevel = maxLevel = 0
+            pos2[i] = make_float2(k2.x, k2.y);
+            cell2[i] = (int16_t)(ok ? cell : -1);
+            matched_dist[i] = 0xFFFF;
+            matches21[i] = 0xFFFF;
+        }
+        const unsigned long long m = __ballot(ok);
+        if (ok) elig[nelig + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = (uint16_t)i;
+        nelig += __popcll(m);
     }
     for (int i = lane; i < n1; i += 64) { bin_of[i] = 0xFF; m12[i] = -1; }
     if (lane < MT_HISTO) s_hist[lane] = 0;
@@ -82,10 +93,10 @@ __global__ __launch_bounds__(64) void k_search_init(const GridKp* __restrict__ k
         // every lane: best and second-best (with multiplicity) over its share of the candidates
         unsigned long long best = ~0ull;                      // distance << 40 | cell << 20 | index
         unsigned second = 0x7FFFFFFFu;
-        for (int i2 = lane; i2 < n2; i2 += 64) {
+        for (int j = lane; j < nelig; j += 64) {
+            const int i2 = elig[j];
             const int cell = cell2[i2];
             const float2 q = pos2[i2];
-            if (cell < 0) continue;
             if (!(fabsf(q.x - p.x) < r && fabsf(q.y - p.y) < r)) continue;
             const uint4* d2p = reinterpret_cast<const uint4*>(desc2 + (o + i2) * 32);
             const uint4 a = d2p[0], b = d2p[1];
