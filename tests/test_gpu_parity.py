@@ -124,3 +124,43 @@ def test_batch_matches_single(mods):
     for i in range(len(imgs)):
         kp, desc = single(imgs[i], fetch_pyramid=False)
         assert np.array_equal(res[i][0], kp) and np.array_equal(res[i][1], desc), i
+
+
+def _random_configs(n, seed):
+    """Deterministic draw of image sizes and extractor parameters over the ranges the tables support."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        w = int(rng.integers(200, 900))
+        h = int(rng.integers(160, 700))
+        nf = int(rng.choice([50, 200, 500, 1000, 1500, 3000]))
+        sf = float(rng.choice([1.1, 1.2, 1.2, 1.25, 1.5, 2.0]))
+        nl = int(rng.integers(1, 11))
+        ini = int(rng.choice([12, 20, 20, 30, 60]))
+        mn = int(rng.choice([3, 5, 7, 7, ini]))
+        kind = str(rng.choice(["blocks", "blocks", "noise", "lowc"]))
+        out.append((w, h, nf, sf, nl, ini, min(mn, ini), kind, 100 + i))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_configs(24, 20240611), ids=lambda c: "%dx%d_n%d_s%.2f_l%d_t%d-%d_%s" % c[:8])
+def test_random_parameters(mods, case):
+    """Sizes, feature counts, scale factors, level counts and thresholds drawn at random: full
+    stage-by-stage parity, or the same refusal as the oracle for shapes neither can process."""
+    orbhip, O = mods
+    w, h, nf, sf, nl, ini, mn, kind, index = case
+    img = synth.frame(kind, w, h, index)
+    o = O.OracleExtractor(nf, sf, nl, ini, mn)
+    g = orbhip.ORBextractor(nf, sf, nl, ini, mn)
+    try:
+        okp, odesc = o.extract(img)
+    except RuntimeError:
+        with pytest.raises(orbhip.OrbHipError):
+            g(img)
+        return
+    gkp, gdesc = g(img)
+    for l in range(nl):
+        assert np.array_equal(g.pyramid_level(l, with_border=True), o.level(l, with_border=True)), "pyramid level %d" % l
+        assert np.array_equal(g.debug_candidates(l), o.candidates(l)), "candidate list of level %d" % l
+    r = compare_outputs(gkp, gdesc, okp, odesc)
+    assert r["desc_exact"] >= DESC_MIN_EXACT, r
