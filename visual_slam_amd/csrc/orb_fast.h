@@ -22,8 +22,9 @@
 //                     edges fail this test; the survivors of a step are compacted into a
 //                     per-wave queue with one wave prefix sum (raw codes, decoded where they
 //                     are consumed). The loaded rows are also copied into an image tile in LDS.
-//   score  (sparse) : queued pixels are taken 64 at a time, one per lane (a remainder waits
-//                     for the next step): 16 ring bytes from the LDS image tile, exact score,
+//   score  (sparse) : queued pixels are taken 128 at a time, two per lane in the halves of packed
+//                     16-bit values (a remainder waits for the next step and the last one is
+//                     taken one per lane if it is small): 16 ring bytes from the LDS image tile, exact score,
 //                     written to a byte map of the tile in LDS, plus one bit per scored pixel
 //                     in an occupancy map.
 //   nms    (sparse) : after a barrier every wave reads the occupancy bits of its 8 map rows,
@@ -80,6 +81,36 @@ __device__ __forceinline__ int fast_score16(int v, const int (&p)[16]) {
         b0 = min(b0, max(hi8, min(d[k], d[(k + 9) & 15])));
     }
     return max(a0, -b0) - 1;
+}
+
+// The same for two pixels at once: every value is a pair of 16-bit halves (packed min / max / sub).
+__device__ __forceinline__ v2s fast_score16_pk(v2s v, const v2s (&p)[16]) {
+    v2s d[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) d[k] = v - p[k];
+    v2s lo2[8], hi2[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        lo2[j] = pmin(d[(2 * j + 1) & 15], d[(2 * j + 2) & 15]);
+        hi2[j] = pmax(d[(2 * j + 1) & 15], d[(2 * j + 2) & 15]);
+    }
+    v2s lo4[8], hi4[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        lo4[j] = pmin(lo2[j], lo2[(j + 1) & 7]);
+        hi4[j] = pmax(hi2[j], hi2[(j + 1) & 7]);
+    }
+    v2s a0 = {-256, -256}, b0 = {256, 256};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int k = 2 * j;
+        const v2s lo8 = pmin(lo4[j], lo4[(j + 2) & 7]);
+        const v2s hi8 = pmax(hi4[j], hi4[(j + 2) & 7]);
+        a0 = pmax(a0, pmin(lo8, pmax(d[k], d[(k + 9) & 15])));
+        b0 = pmin(b0, pmax(hi8, pmin(d[k], d[(k + 9) & 15])));
+    }
+    const v2s one = {1, 1}, zero = {0, 0};
+    return pmax(a0, zero - b0) - one;
 }
 
 #define FT_COLS 248        // output columns per tile (62 lanes x 4; lanes 0 and 63 are halo)
@@ -142,6 +173,33 @@ __device__ __forceinline__ void fast_score_queue(const uint16_t* queue, int n, i
     }
 }
 
+// Scores `n` (64 < n <= 128) queued pixels, two per lane (entries lane and lane + 64), with packed
+// 16-bit arithmetic. A lane without a second entry scores its first one twice.
+__device__ __forceinline__ void fast_score_queue2(const uint16_t* queue, int n, int lane, int m0, const uint8_t* img,
+                                                  int min_th, uint8_t* map, uint32_t* occ) {
+    const bool two = lane + 64 < n;
+    const uint32_t ea = queue[lane], eb = queue[two ? lane + 64 : lane];
+    const int xa = (int)((ea >> 3) & 0xFC) + (int)((ea >> 3) & 3), xb = (int)((eb >> 3) & 0xFC) + (int)((eb >> 3) & 3);
+    const int ra = m0 + FT_GROUP * (int)(ea >> 11) + (int)(~ea & 7), rb = m0 + FT_GROUP * (int)(eb >> 11) + (int)(~eb & 7);
+    const uint8_t* ca = img + (ra + 3) * FT_P + xa;
+    const uint8_t* cb = img + (rb + 3) * FT_P + xb;
+    constexpr int ring[16] = {3 * FT_P, 3 * FT_P + 1, 2 * FT_P + 2, FT_P + 3, 3, -FT_P + 3, -2 * FT_P + 2, -3 * FT_P + 1,
+                              -3 * FT_P, -3 * FT_P - 1, -2 * FT_P - 2, -FT_P - 3, -3, FT_P - 3, 2 * FT_P - 2, 3 * FT_P - 1};
+    v2s p[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) p[k] = v2s{(short)ca[ring[k]], (short)cb[ring[k]]};
+    const v2s v = {(short)ca[0], (short)cb[0]};
+    const v2s s = fast_score16_pk(v, p);
+    if (s.x >= min_th) {
+        map[ra * FT_P + xa] = (uint8_t)s.x;
+        atomicOr(&occ[ra * 8 + (xa >> 5)], 1u << (xa & 31));
+    }
+    if (two && s.y >= min_th) {
+        map[rb * FT_P + xb] = (uint8_t)s.y;
+        atomicOr(&occ[rb * 8 + (xb >> 5)], 1u << (xb & 31));
+    }
+}
+
 // Grid: (tiles in x, tiles in y, frames). Output: segment (tile, wave) of FT_SEGCAP entries
 // {x | y << 16 (relative to the detection window origin (16,16)), score} and its entry count.
 __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, LevelGeom g, int min_th,
@@ -195,7 +253,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
         const uint32_t off = (uint32_t)((ORB_OY + min(y, y_last)) * g.pitch) + coff;   // a plane is far below 4 GB
         return *reinterpret_cast<const uint32_t*>(plane + off);
     };
-    int pending = 0;                                           // queued pixels not scored yet (wave-uniform, < 64 between steps)
+    int pending = 0;                                           // queued pixels not scored yet (wave-uniform, < 128 between steps)
 #pragma unroll 1
     for (int grp = 0; grp < 2; grp++) {
         const int mg = m0 + FT_GROUP * grp;                    // first map row of this step
@@ -258,20 +316,21 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
         // one word: byte i = pixel i, bit 7-j of the byte = row j
         const uint32_t verdict = __builtin_amdgcn_perm(acc1, acc0, 0x07050301u) & ok_mask;
         // exact scores of the survivors (their rings lie in tile rows this wave has just written)
-        // Only full batches of 64 are scored here; the remainder waits in the queue for the next step.
+        // Only full batches of 128 are scored here; the remainder waits in the queue for the next step.
         if (__ballot(verdict != 0)) {
             const uint32_t cnt = __popc(verdict);
             const uint32_t incl = wave_scan_incl(cnt);
             const int total = (int)__shfl(incl, 63, 64);
             const int first = (int)(incl - cnt);
             const uint32_t code0 = ((uint32_t)grp << 11) | ((uint32_t)lane << 5);
-            auto drain = [&](int n) {                          // n entries queued: score the full batches
-                const int nfull = n & ~63;
-                for (int q = 0; q < nfull; q += 64) fast_score_queue(queue + q, 64, lane, m0, s_img, min_th, s_map, s_occ);
+            auto drain = [&](int n) {                          // n entries queued: score the full double batches
+                const int nfull = n & ~127;
+                for (int q = 0; q < nfull; q += 128) fast_score_queue2(queue + q, 128, lane, m0, s_img, min_th, s_map, s_occ);
                 pending = n - nfull;
-                if (nfull && lane < pending) {
-                    const uint16_t v = queue[nfull + lane];
-                    queue[lane] = v;
+                if (nfull) {                                   // move the remainder (< 128 entries) to the front
+                    const uint16_t v0 = queue[nfull + lane], v1 = queue[min(nfull + 64 + lane, FT_QUEUE - 1)];
+                    if (lane < pending) queue[lane] = v0;
+                    if (lane + 64 < pending) queue[64 + lane] = v1;
                 }
             };
             if (pending + total <= FT_QUEUE) {
@@ -287,7 +346,8 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
             }
         }
     }
-    if (pending) fast_score_queue(queue, pending, lane, m0, s_img, min_th, s_map, s_occ);
+    if (pending > 64) fast_score_queue2(queue, pending, lane, m0, s_img, min_th, s_map, s_occ);
+    else if (pending) fast_score_queue(queue, pending, lane, m0, s_img, min_th, s_map, s_occ);
     __syncthreads();                                           // all scores of the tile are in the map
 
     // ---- non-maximum suppression inside the cell and emission, map rows 1+8*wv .. 8+8*wv
