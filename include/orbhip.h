@@ -208,6 +208,52 @@ int orbhip_search_for_initialization(orbhip_extractor* e, const orbhip_keypoint*
                                      float* prev_matched, int window_size, float nnratio, int check_orientation,
                                      int* matches12, int* nmatches);
 
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)
+ * (src/ORBmatcher.cc:1324-1445), the matcher of Tracking::TrackWithMotionModel (src/Tracking.cc:1332,1337),
+ * for `nframes` (last, current) frame pairs in device memory. Frames and map points stay with the
+ * caller; the call sees them as arrays of [nframes][cap] records:
+ *   last frame     d_kp_last     mvKeysUn (octave and angle are read)
+ *                  d_world_last  GetWorldPos() of mvpMapPoints[i], 3 floats
+ *                  d_flags_last  bit 0: mvpMapPoints[i] exists and mvbOutlier[i] is false;
+ *                                bit 1: that point has Observations() > 0
+ *                  d_desc_last   GetDescriptor() of the point, 32 bytes
+ *   current frame  d_kp_cur      mvKeysUn;  d_desc_cur  mDescriptors;
+ *                  d_uright_cur  mvuRight, or NULL for a monocular frame (all -1)
+ *   d_Tcw          [nframes][12] CurrentFrame.mTcw as Rcw (row-major) followed by tcw
+ *   d_level_mode   [nframes] 0 / 1 (bForward) / 2 (bBackward) as orbhip_projection_level_mode
+ *                  returns it, or NULL for 0 everywhere (a monocular tracker)
+ * CurrentFrame.mvpMapPoints is taken to be all NULL on entry, as the caller leaves it
+ * (src/Tracking.cc:1323,1336). d_match_cur[nframes][cap] receives, per current keypoint, the index
+ * of the last-frame keypoint whose map point it was given, or -1 (the caller stores
+ * LastFrame.mvpMapPoints[index] there); d_nmatches[nframes] the return value. The scale factors
+ * are those of the handle `e` (CurrentFrame.mvScaleFactors). The fork's bounding-box bookkeeping
+ * inside the loop (matches_in_box, points_in_box, src/ORBmatcher.cc:1401-1408) does not influence
+ * the matching and stays with the caller. */
+typedef struct orbhip_projection_params {
+    float fx, fy, cx, cy;     /* CurrentFrame.fx .. cy */
+    float mbf;                /* CurrentFrame.mbf */
+    float bounds[4];          /* mnMinX, mnMaxX, mnMinY, mnMaxY (orbhip_image_bounds) */
+    float th;                 /* window factor: 15 mono / 7 stereo, doubled on the retry (src/Tracking.cc:1327-1337) */
+    int check_orientation;    /* mbCheckOrientation */
+} orbhip_projection_params;
+int orbhip_search_by_projection_batch_device(orbhip_extractor* e, int nframes, int cap,
+                                             const orbhip_keypoint* d_kp_last, const float* d_world_last,
+                                             const uint8_t* d_flags_last, const uint8_t* d_desc_last, const int* d_cnt_last,
+                                             const orbhip_keypoint* d_kp_cur, const uint8_t* d_desc_cur,
+                                             const float* d_uright_cur, const int* d_cnt_cur, const float* d_Tcw,
+                                             const int* d_level_mode, const orbhip_projection_params* prm,
+                                             int* d_match_cur, int* d_nmatches, void* stream);
+/* The same for one pair with host arrays (n1 last-frame and n2 current keypoints); waits for the result. */
+int orbhip_search_by_projection(orbhip_extractor* e, const orbhip_keypoint* kp_last, const float* world_last,
+                                const uint8_t* flags_last, const uint8_t* desc_last, int n1,
+                                const orbhip_keypoint* kp_cur, const uint8_t* desc_cur, const float* uright_cur, int n2,
+                                const float* Tcw, int level_mode, const orbhip_projection_params* prm,
+                                int* match_cur, int* nmatches);
+/* bForward / bBackward of the same function (src/ORBmatcher.cc:1330-1337) from the two poses
+ * (12 floats each: R row-major, t), the baseline mb and bMono: 0 neither, 1 forward, 2 backward.
+ * Host only. */
+int orbhip_projection_level_mode(const float* Tcw_cur, const float* Tcw_last, float mb, int mono);
+
 const char* orbhip_strerror(int code);
 const char* orbhip_last_error(const orbhip_extractor* e);
 

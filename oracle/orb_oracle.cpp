@@ -1092,4 +1092,166 @@ int orbo_search_for_initialization(const orbo_keypoint* k1, const uint8_t* d1, i
     return nmatches;
 }
 
+/* bForward / bBackward of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono)
+ * (src/ORBmatcher.cc:1330-1337): twc = -Rcw^T tcw, tlc = Rlw twc + tlw (cv::Mat products of CV_32F
+ * matrices: accumulated in double, stored as float); forward when tlc.z > mb, backward when
+ * -tlc.z > mb, neither for a monocular frame. T* = {R row-major (9), t (3)} of mTcw.
+ * Returns 0 (neither), 1 (forward) or 2 (backward; the reference tests forward first). */
+int orbo_projection_level_mode(const float* Tcw_cur, const float* Tcw_last, float mb, int bMono) {
+    float twc[3];
+    for (int r = 0; r < 3; r++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)Tcw_cur[3 * k + r] * (double)Tcw_cur[9 + k];
+        twc[r] = (float)(-s);
+    }
+    double s = 0;
+    for (int k = 0; k < 3; k++) s += (double)Tcw_last[6 + k] * (double)twc[k];
+    const float tlc_z = (float)(s + (double)Tcw_last[11]);
+    if (bMono) return 0;
+    if (tlc_z > mb) return 1;
+    if (-tlc_z > mb) return 2;
+    return 0;
+}
+
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)
+ * (src/ORBmatcher.cc:1324-1445; the matcher of Tracking::TrackWithMotionModel, src/Tracking.cc:1332,1337)
+ * on plain arrays. Last frame, n1 keypoints: k_last = mvKeysUn (octave and angle are read),
+ * world_last = GetWorldPos() of mvpMapPoints[i] (x, y, z), desc_last = its GetDescriptor(),
+ * flags_last bit 0 = "mvpMapPoints[i] exists and mvbOutlier[i] is false", bit 1 = "its
+ * Observations() > 0". Current frame, n2 keypoints: k_cur = mvKeysUn, desc_cur = mDescriptors,
+ * uright_cur = mvuRight (NULL: all -1, a monocular frame); Tcw = {Rcw row-major, tcw};
+ * cam = {fx, fy, cx, cy}; bounds = {mnMinX, mnMaxX, mnMinY, mnMaxY}; scale_factors = mvScaleFactors;
+ * level_mode as orbo_projection_level_mode returns it. CurrentFrame.mvpMapPoints is all NULL on
+ * entry (src/Tracking.cc:1323,1336); match_cur[i2] receives the index i of the last-frame keypoint
+ * whose map point was assigned to current keypoint i2, or -1. Returns nmatches.
+ * Rcw * x3Dw + tcw is OpenCV's small-matrix product for CV_32F (three float products summed in float,
+ * the translation added in double, one rounding to float). The fork's bounding-box bookkeeping
+ * (matches_in_box, points_in_box) does not influence the matching and is not restated. */
+int orbo_search_by_projection(const orbo_keypoint* k_last, const float* world_last, const uint8_t* flags_last,
+                              const uint8_t* desc_last, int n1, const orbo_keypoint* k_cur, const uint8_t* desc_cur,
+                              const float* uright_cur, int n2, const float* Tcw, const float* cam, float mbf,
+                              const float* bounds, const float* scale_factors, float th, int level_mode,
+                              int mbCheckOrientation, int* match_cur) {
+    const int COLS = 64, ROWS = 48, HISTO_LENGTH = 30, TH_HIGH = 100;
+    const float mnMinX = bounds[0], mnMaxX = bounds[1], mnMinY = bounds[2], mnMaxY = bounds[3];
+    const float wInv = static_cast<float>(COLS) / (mnMaxX - mnMinX);
+    const float hInv = static_cast<float>(ROWS) / (mnMaxY - mnMinY);
+    const float fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3];
+    std::vector<std::vector<size_t>> mGrid((size_t)COLS * ROWS);
+    for (int i = 0; i < n2; i++) {
+        const int posX = (int)std::round((k_cur[i].x - mnMinX) * wInv);
+        const int posY = (int)std::round((k_cur[i].y - mnMinY) * hInv);
+        if (posX < 0 || posX >= COLS || posY < 0 || posY >= ROWS) continue;
+        mGrid[(size_t)posX * ROWS + posY].push_back((size_t)i);
+    }
+    auto GetFeaturesInArea = [&](float x, float y, float r, int minLevel, int maxLevel) {   /* src/Frame.cc:351-401 */
+        std::vector<size_t> vIndices;
+        const int nMinCellX = std::max(0, (int)std::floor((x - mnMinX - r) * wInv));
+        if (nMinCellX >= COLS) return vIndices;
+        const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((x - mnMinX + r) * wInv));
+        if (nMaxCellX < 0) return vIndices;
+        const int nMinCellY = std::max(0, (int)std::floor((y - mnMinY - r) * hInv));
+        if (nMinCellY >= ROWS) return vIndices;
+        const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((y - mnMinY + r) * hInv));
+        if (nMaxCellY < 0) return vIndices;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                const std::vector<size_t>& vCell = mGrid[(size_t)ix * ROWS + iy];
+                for (size_t j = 0; j < vCell.size(); j++) {
+                    const orbo_keypoint& kpUn = k_cur[vCell[j]];
+                    if (bCheckLevels) {
+                        if (kpUn.octave < minLevel) continue;
+                        if (maxLevel >= 0 && kpUn.octave > maxLevel) continue;
+                    }
+                    const float distx = kpUn.x - x, disty = kpUn.y - y;
+                    if (std::fabs(distx) < r && std::fabs(disty) < r) vIndices.push_back(vCell[j]);
+                }
+            }
+        return vIndices;
+    };
+    auto DescriptorDistance = [](const uint8_t* a, const uint8_t* b) {   /* src/ORBmatcher.cc:1611-1627 */
+        int dist = 0;
+        for (int i = 0; i < 8; i++) {
+            uint32_t pa, pb;
+            std::memcpy(&pa, a + 4 * i, 4); std::memcpy(&pb, b + 4 * i, 4);
+            unsigned int v = pa ^ pb;
+            v = v - ((v >> 1) & 0x55555555);
+            v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+            dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+        }
+        return dist;
+    };
+    int nmatches = 0;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    /* CurrentFrame.mvpMapPoints: index of the last-frame keypoint whose point sits there, -1 = NULL */
+    for (int i = 0; i < n2; i++) match_cur[i] = -1;
+    for (int i = 0; i < n1; i++) {
+        if (!(flags_last[i] & 1)) continue;                    /* pMP && !mvbOutlier[i] */
+        const float* X = world_last + 3 * (size_t)i;
+        float x3Dc[3];
+        for (int r = 0; r < 3; r++) {
+            const float t = Tcw[3 * r] * X[0] + Tcw[3 * r + 1] * X[1] + Tcw[3 * r + 2] * X[2];
+            x3Dc[r] = (float)((double)t * 1.0 + (double)Tcw[9 + r] * 1.0);
+        }
+        const float xc = x3Dc[0], yc = x3Dc[1];
+        const float invzc = (float)(1.0 / x3Dc[2]);
+        if (invzc < 0) continue;
+        float u = fx * xc * invzc + cx;
+        float v = fy * yc * invzc + cy;
+        if (!(u == u) || !(v == v)) continue;                  /* a point in the camera centre: undefined in the reference */
+        if (u < mnMinX || u > mnMaxX) continue;
+        if (v < mnMinY || v > mnMaxY) continue;
+        const int nLastOctave = k_last[i].octave;
+        const float radius = th * scale_factors[nLastOctave];
+        std::vector<size_t> vIndices2;
+        if (level_mode == 1) vIndices2 = GetFeaturesInArea(u, v, radius, nLastOctave, -1);
+        else if (level_mode == 2) vIndices2 = GetFeaturesInArea(u, v, radius, 0, nLastOctave);
+        else vIndices2 = GetFeaturesInArea(u, v, radius, nLastOctave - 1, nLastOctave + 1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* dMP = desc_last + 32 * (size_t)i;
+        int bestDist = 256, bestIdx2 = -1;
+        for (size_t i2 : vIndices2) {
+            if (match_cur[i2] >= 0 && (flags_last[match_cur[i2]] & 2)) continue;   /* a point with observations sits there */
+            const float ur2 = uright_cur ? uright_cur[i2] : -1.0f;
+            if (ur2 > 0) {
+                const float ur = u - mbf * invzc;
+                const float er = std::fabs(ur - ur2);
+                if (er > radius) continue;
+            }
+            const int dist = DescriptorDistance(dMP, desc_cur + 32 * i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            match_cur[bestIdx2] = i;
+            nmatches++;
+            if (mbCheckOrientation) {
+                float rot = k_last[i].angle - k_cur[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        int max1 = 0, max2 = 0, max3 = 0;                      /* ComputeThreeMaxima (src/ORBmatcher.cc:1566-1607) */
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int sz = (int)rotHist[i].size();
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx2 : rotHist[i]) { match_cur[idx2] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 } // extern "C"

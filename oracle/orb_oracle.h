@@ -119,6 +119,16 @@ int orbo_search_for_initialization(const orbo_keypoint* k1, const uint8_t* d1, i
                                    float* prev_matched, int windowSize, float mfNNratio, int mbCheckOrientation,
                                    int* matches12);
 
+/* ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1324-1445) on
+ * plain arrays; see orb_oracle.cpp for the meaning of every argument. Returns nmatches. */
+int orbo_search_by_projection(const orbo_keypoint* k_last, const float* world_last, const uint8_t* flags_last,
+                              const uint8_t* desc_last, int n1, const orbo_keypoint* k_cur, const uint8_t* desc_cur,
+                              const float* uright_cur, int n2, const float* Tcw, const float* cam, float mbf,
+                              const float* bounds, const float* scale_factors, float th, int level_mode,
+                              int mbCheckOrientation, int* match_cur);
+/* bForward / bBackward of the same function (src/ORBmatcher.cc:1330-1337): 0 neither, 1 forward, 2 backward. */
+int orbo_projection_level_mode(const float* Tcw_cur, const float* Tcw_last, float mb, int bMono);
+
 /* Frame::ComputeStereoMatches (reference src/Frame.cc:481-653) on the last extractions of a left and
  * a right instance: kl/dl/nl and kr/dr/nr are their keypoints and descriptors, mb / mbf the stereo
  * baseline (metres) and baseline times fx. uright[nl] / depth[nl] receive mvuRight / mvDepth

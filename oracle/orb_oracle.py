@@ -77,6 +77,10 @@ def lib():
         L.orbo_undistort_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orbo_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                      C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.orbo_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                                C.c_float, C.c_int, C.c_int, C.c_void_p]
+        L.orbo_projection_level_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int]
         L.orbo_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
@@ -217,6 +221,33 @@ def search_for_initialization(kp1, desc1, kp2, desc2, bounds, prev_matched, wind
                                              _ptr(np.ascontiguousarray(bounds, np.float32)), _ptr(prev), int(window),
                                              float(nnratio), int(bool(check_orientation)), _ptr(m12))
     return m12[:len(kp1)], prev, n
+
+
+def projection_level_mode(Tcw_cur, Tcw_last, mb, mono):
+    """bForward / bBackward of SearchByProjection(CurrentFrame, LastFrame): 0 neither, 1 forward, 2 backward.
+    T* = 12 floats: Rcw row-major, then tcw."""
+    a = np.ascontiguousarray(Tcw_cur, np.float32).reshape(12); b = np.ascontiguousarray(Tcw_last, np.float32).reshape(12)
+    return lib().orbo_projection_level_mode(_ptr(a), _ptr(b), float(mb), int(bool(mono)))
+
+
+def search_by_projection(kp_last, world_last, flags_last, desc_last, kp_cur, desc_cur, uright_cur, Tcw, cam4, mbf, bounds,
+                         scale_factors, th, level_mode=0, check_orientation=True):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono): returns (match_cur, nmatches) with
+    match_cur[i2] = index of the last-frame keypoint whose map point current keypoint i2 received, or -1."""
+    kp_last = np.ascontiguousarray(kp_last, KP_DTYPE); kp_cur = np.ascontiguousarray(kp_cur, KP_DTYPE)
+    world = np.ascontiguousarray(world_last, np.float32).reshape(-1, 3)
+    flags = np.ascontiguousarray(flags_last, np.uint8)
+    d1 = np.ascontiguousarray(desc_last, np.uint8); d2 = np.ascontiguousarray(desc_cur, np.uint8)
+    ur = None if uright_cur is None else np.ascontiguousarray(uright_cur, np.float32)
+    m = np.full(max(len(kp_cur), 1), -1, np.int32)
+    n = lib().orbo_search_by_projection(_ptr(kp_last), _ptr(world), _ptr(flags), _ptr(d1), len(kp_last), _ptr(kp_cur), _ptr(d2),
+                                        None if ur is None else _ptr(ur), len(kp_cur),
+                                        _ptr(np.ascontiguousarray(Tcw, np.float32).reshape(12)),
+                                        _ptr(np.ascontiguousarray(cam4, np.float32)), float(mbf),
+                                        _ptr(np.ascontiguousarray(bounds, np.float32)),
+                                        _ptr(np.ascontiguousarray(scale_factors, np.float32)), float(th), int(level_mode),
+                                        int(bool(check_orientation)), _ptr(m))
+    return m[:len(kp_cur)], n
 
 
 def cvt_gray(img, rgb):

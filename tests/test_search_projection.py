@@ -1,0 +1,146 @@
+"""ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (reference
+src/ORBmatcher.cc:1324-1445): oracle properties on a frame pair whose camera motion is known, and GPU
+parity. The scene is a fronto-parallel plane at depth Z seen by a camera that moves sideways, so the
+image moves by a constant (dx, dy)."""
+import numpy as np
+import pytest
+
+from visual_slam_amd import synth
+
+KITTI = (718.856, 718.856, 607.1928, 185.2157, 0.0, 0.0, 0.0, 0.0, 0.0)
+TUM1 = (517.306408, 516.469215, 318.643040, 255.313989, 0.262383, -0.953104, -0.005358, 0.002628, 1.163314)
+Z = 6.0
+
+
+def shifted(img, dx, dy):
+    out = img.copy()
+    h, w = img.shape
+    out[max(dy, 0):h + min(dy, 0), max(dx, 0):w + min(dx, 0)] = img[max(-dy, 0):h + min(-dy, 0), max(-dx, 0):w + min(-dx, 0)]
+    return out
+
+
+def scenario(w, h, index, dx, dy, cam, stereo=False, seed=7, prm=(2000, 1.2, 8, 20, 7)):
+    from oracle import orb_oracle as O
+    a = synth.frame("blocks", w, h, index)
+    b = shifted(a, dx, dy)
+    e = O.OracleExtractor(*prm)
+    k1, d1 = e.extract(a)
+    k2, d2 = e.extract(b)
+    bounds = O.image_bounds(cam, w, h)
+    u1 = O.undistort_grid(cam, bounds, k1)[0]
+    u2 = O.undistort_grid(cam, bounds, k2)[0]
+    fx, fy, cx, cy = cam[:4]
+    # last camera frame = world frame; every point on the plane z = Z
+    world = np.stack([(u1["x"] - cx) * Z / fx, (u1["y"] - cy) * Z / fy, np.full(len(u1), Z)], axis=1).astype(np.float32)
+    Tcw = np.concatenate([np.eye(3).ravel(), [dx * Z / fx, dy * Z / fy, 0.0]]).astype(np.float32)
+    rng = np.random.default_rng(seed)
+    flags = (rng.random(len(u1)) < 0.85).astype(np.uint8)             # has a map point that is no outlier
+    flags |= ((rng.random(len(u1)) < 0.8).astype(np.uint8) << 1)       # that point has observations
+    mbf = 0.5 * fx                                                      # 0.5 m baseline
+    uright = None
+    if stereo:
+        uright = (u2["x"] - mbf / Z).astype(np.float32)
+        uright[rng.random(len(u2)) < 0.3] = -1.0                        # no stereo match there
+        wrong = rng.random(len(u2)) < 0.1
+        uright[wrong] += 40.0                                           # a right coordinate that contradicts the depth
+    return dict(u1=u1, d1=d1, u2=u2, d2=d2, world=world, flags=flags, Tcw=Tcw, cam4=np.array(cam[:4], np.float32), mbf=mbf,
+                bounds=bounds, sf=e.table(0), uright=uright)
+
+
+def run_oracle(s, th, mode, ori):
+    from oracle import orb_oracle as O
+    return O.search_by_projection(s["u1"], s["world"], s["flags"], s["d1"], s["u2"], s["d2"], s["uright"], s["Tcw"], s["cam4"],
+                                  s["mbf"], s["bounds"], s["sf"], th, mode, ori)
+
+
+def test_oracle_follows_a_known_motion():
+    s = scenario(640, 480, 71, 9, -6, KITTI)
+    m, n = run_oracle(s, 15, 0, True)
+    got = m >= 0
+    # the return value also counts assignments that a later point overwrote (only points without
+    # observations can be overwritten)
+    assert n > 300 and got.sum() <= n <= got.sum() + ((s["flags"] & 3) == 1).sum()
+    s_all = dict(s, flags=s["flags"] | 2)
+    m_all, n_all = run_oracle(s_all, 15, 0, True)
+    assert n_all == (m_all >= 0).sum()
+    # only keypoints with a usable map point are matched, and they land where the motion says
+    assert np.all(s["flags"][m[got]] & 1)
+    ex = s["u2"]["x"][got] - s["u1"]["x"][m[got]]
+    ey = s["u2"]["y"][got] - s["u1"]["y"][m[got]]
+    tol = 2.0 * s["sf"][s["u2"]["octave"][got]]                # a pixel or two of the keypoint's own pyramid level
+    assert np.mean((np.abs(ex - 9) <= tol) & (np.abs(ey + 6) <= tol)) > 0.8    # TH_HIGH = 100 and no ratio test: some wrong matches
+    # the octave of a match stays within one level of the last frame's
+    assert np.all(np.abs(s["u2"]["octave"][got] - s["u1"]["octave"][m[got]]) <= 1)
+    # with a pose that predicts no motion a narrow window misses the 11-px shift on the fine levels
+    still = dict(s, Tcw=np.concatenate([np.eye(3).ravel(), [0, 0, 0]]).astype(np.float32))
+    ms, ns = run_oracle(still, 3, 0, True)
+    assert ns < n // 2
+    # forward / backward motion restricts the octaves to one side
+    mf, _ = run_oracle(s, 15, 1, False)
+    mb_, _ = run_oracle(s, 15, 2, False)
+    gf, gb = mf >= 0, mb_ >= 0
+    assert np.all(s["u2"]["octave"][gf] >= s["u1"]["octave"][mf[gf]])
+    assert np.all(s["u2"]["octave"][gb] <= s["u1"]["octave"][mb_[gb]])
+
+
+def test_oracle_respects_right_coordinates():
+    s = scenario(752, 480, 72, 7, 2, KITTI, stereo=True)
+    m, n = run_oracle(s, 7, 0, True)
+    got = m >= 0
+    assert n > 200
+    # a current keypoint whose right coordinate contradicts the projected depth is not taken
+    pred = s["u1"]["x"][m[got]] + 7 - s["mbf"] / Z
+    ur = s["uright"][got]
+    radius = 7 * s["sf"][s["u1"]["octave"][m[got]]]
+    assert np.all((ur <= 0) | (np.abs(pred - ur) <= radius + 1.0))
+
+
+def test_level_mode_from_poses():
+    from oracle import orb_oracle as O
+    I = np.eye(3).ravel()
+    last = np.concatenate([I, [0, 0, 0]])
+    fwd = np.concatenate([I, [0, 0, -1.0]])      # camera centre moved to z = +1 in the world = last frame
+    back = np.concatenate([I, [0, 0, 1.0]])
+    side = np.concatenate([I, [1.0, 0, 0]])
+    assert O.projection_level_mode(fwd, last, 0.5, False) == 1
+    assert O.projection_level_mode(back, last, 0.5, False) == 2
+    assert O.projection_level_mode(side, last, 0.5, False) == 0
+    assert O.projection_level_mode(fwd, last, 0.5, True) == 0      # monocular: never
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cam,w,h,dx,dy,stereo,th,mode,ori", [
+    (KITTI, 1241, 376, 9, 3, True, 7, 0, True),
+    (TUM1, 640, 480, -11, 8, False, 15, 0, True),
+    (KITTI, 752, 480, 14, -5, True, 14, 1, False),
+    (KITTI, 640, 480, 4, 4, False, 30, 2, True),
+])
+def test_hip_search_by_projection_matches_oracle(cam, w, h, dx, dy, stereo, th, mode, ori):
+    from visual_slam_amd import orbhip
+    s = scenario(w, h, 73, dx, dy, cam, stereo=stereo)
+    om, on = run_oracle(s, th, mode, ori)
+    ex = orbhip.ORBextractor(2000, 1.2, 8, 20, 7)
+    gm, gn = orbhip.SearchByProjection(ex, s["u1"], s["world"], s["flags"], s["d1"], s["u2"], s["d2"], s["uright"], s["Tcw"],
+                                       s["cam4"], s["mbf"], s["bounds"], th, mode, ori)
+    assert on > 100 and gn == on
+    assert np.array_equal(gm, om)
+
+
+@pytest.mark.gpu
+def test_hip_search_by_projection_contested_keypoints():
+    """Every last-frame keypoint twice: the copies compete for the same current keypoints, so the
+    'a point with observations already sits there' rule and the overwrite of points without
+    observations decide most matches."""
+    from visual_slam_amd import orbhip
+    s = scenario(640, 480, 74, 5, 0, KITTI, prm=(1200, 1.2, 8, 20, 7))
+    for k in ("u1", "world", "flags", "d1"):
+        s[k] = np.concatenate([s[k], s[k]])
+    rng = np.random.default_rng(3)
+    s["flags"] = (s["flags"] & 1) | ((rng.random(len(s["flags"])) < 0.5).astype(np.uint8) << 1)
+    om, on = run_oracle(s, 15, 0, True)
+    ex = orbhip.ORBextractor(1200, 1.2, 8, 20, 7)
+    gm, gn = orbhip.SearchByProjection(ex, s["u1"], s["world"], s["flags"], s["d1"], s["u2"], s["d2"], None, s["Tcw"],
+                                       s["cam4"], s["mbf"], s["bounds"], 15, 0, True)
+    assert gn == on and np.array_equal(gm, om)
+    assert on > (om >= 0).sum()                                  # overwritten assignments still count, as in the reference
+    assert orbhip.ProjectionLevelMode(s["Tcw"], np.concatenate([np.eye(3).ravel(), [0, 0, 0]]), 0.5, False) == 0

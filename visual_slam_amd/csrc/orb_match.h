@@ -162,3 +162,232 @@ __global__ __launch_bounds__(64) void k_search_init(const GridKp* __restrict__ k
     for (int s = 32; s > 0; s >>= 1) count += __shfl_xor(count, s, 64);
     if (lane == 0) nmatches_out[f] = count;
 }
+
+// ------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)
+// (reference src/ORBmatcher.cc:1324-1445; Tracking::TrackWithMotionModel, src/Tracking.cc:1332,1337)
+// on plain arrays: the map points seen by the last frame are projected with the current pose and
+// matched against the current keypoints inside a window (Frame::GetFeaturesInArea, src/Frame.cc:351-401).
+//
+// The reference loop over the last frame's keypoints is sequential only through one rule: a
+// current keypoint that already holds a point with observations is skipped. The kernel therefore
+// splits the work. First every last-frame keypoint finds, in parallel, its best candidate with that
+// rule ignored (one wave per keypoint, lanes over the grid cells of the window; the current
+// keypoints are bucketed by grid cell in LDS first). Then one wave walks the keypoints in order:
+// if the best candidate is still free it is the reference's answer (the minimum over a superset
+// that lies in the subset), otherwise the search is repeated with the rule applied. The traversal
+// order of the reference (cells by column then row, indices ascending inside a cell, first of equal
+// distances wins) is the minimum over (distance, cell, index).
+// One workgroup (4 waves) per frame pair.
+// ------------------------------------------------------------------------------------------------
+#define MP_TH_HIGH 100        // ORBmatcher::TH_HIGH (src/ORBmatcher.cc:38)
+#define MP_LDS_PER_KP 38      // dynamic LDS bytes per keypoint slot (see the carve-up below)
+#define MP_NONE 0xFFFFFFFFu
+
+struct ScaleTab { float v[ORB_MAX_LEVELS]; };                 // mvScaleFactors
+
+struct ProjArgs {
+    float fx, fy, cx, cy, mbf;
+    float min_x, max_x, min_y, max_y, inv_w, inv_h;
+    float th;
+    int check_orientation;
+};
+
+__global__ __launch_bounds__(256) void k_search_proj(const GridKp* __restrict__ kp1, const float* __restrict__ world1,
+                                                     const uint8_t* __restrict__ flags1, const uint8_t* __restrict__ desc1,
+                                                     const int* __restrict__ cnt1, const GridKp* __restrict__ kp2,
+                                                     const uint8_t* __restrict__ desc2, const float* __restrict__ uright2,
+                                                     const int* __restrict__ cnt2, int cap, const float* __restrict__ Tcw,
+                                                     const int* __restrict__ level_mode, ProjArgs a, ScaleTab sf,
+                                                     int* __restrict__ match2, int* __restrict__ nmatches_out) {
+    extern __shared__ __align__(16) uint8_t mp_smem[];
+    float2* pos2 = reinterpret_cast<float2*>(mp_smem);                       // current keypoints: position
+    float2* uv1 = pos2 + cap;                                                // last keypoints: projection (u, v)
+    float* ur2 = reinterpret_cast<float*>(uv1 + cap);                        // current: mvuRight
+    float* ur1 = ur2 + cap;                                                  // last: u - mbf / z
+    uint32_t* best1 = reinterpret_cast<uint32_t*>(ur1 + cap);                // last: distance << 16 | current index, occupancy ignored
+    uint16_t* sorted2 = reinterpret_cast<uint16_t*>(best1 + cap);            // current indices bucketed by grid cell
+    uint16_t* cell2 = sorted2 + cap;                                         // current: grid cell, 0xFFFF = outside
+    uint16_t* taken1 = cell2 + cap;                                          // last: the current keypoint it was assigned to
+    uint8_t* oct2 = reinterpret_cast<uint8_t*>(taken1 + cap);                // current: octave
+    uint8_t* occ2 = oct2 + cap;                                              // current: holds a point with observations
+    uint8_t* st1 = occ2 + cap;                                               // last: 1 usable | 2 observed | octave << 2
+    uint8_t* bin1 = st1 + cap;                                               // last: rotation bin of its match, 0xFF = none
+    __shared__ uint32_t s_cur[GRID_CELLS];                                   // histogram, then running cursor
+    __shared__ uint16_t s_start[GRID_CELLS + 2];
+    __shared__ uint32_t s_magic[GRID_ROWS + 1];
+    __shared__ uint32_t s_tmp[4];
+    __shared__ int s_hist[MT_HISTO];
+    __shared__ int s_made;
+    const int tid = threadIdx.x, lane = tid & 63, f = blockIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t o = (size_t)f * cap;
+    const int n1 = min(cnt1[f], cap), n2 = min(cnt2[f], cap);
+    const GridKp* K1 = kp1 + o;
+    const GridKp* K2 = kp2 + o;
+    const int mode = level_mode ? level_mode[f] : 0;
+    const float* T = Tcw + 12 * (size_t)f;
+    int* m2 = match2 + o;
+
+    for (int c = tid; c < GRID_CELLS; c += 256) s_cur[c] = 0;
+    if (tid >= 1 && tid <= GRID_ROWS) s_magic[tid] = ((1u << 20) + tid - 1) / tid;   // n / d == n * magic >> 20 for n * d < 2^20
+    if (tid < MT_HISTO) s_hist[tid] = 0;
+    if (tid == 0) s_made = 0;
+    __syncthreads();
+    for (int i = tid; i < n2; i += 256) {
+        const GridKp k = K2[i];
+        const int cell = grid_cell(k.x, k.y, a.min_x, a.min_y, a.inv_w, a.inv_h);
+        pos2[i] = make_float2(k.x, k.y);
+        ur2[i] = uright2 ? uright2[o + i] : -1.0f;
+        cell2[i] = (uint16_t)(cell < 0 ? 0xFFFF : cell);
+        oct2[i] = (uint8_t)k.octave;
+        occ2[i] = 0;
+        m2[i] = -1;                                            // CurrentFrame.mvpMapPoints is all NULL on entry
+        if (cell >= 0) atomicAdd(&s_cur[cell], 1u);
+    }
+    // projections of the last frame's map points (src/ORBmatcher.cc:1343-1361)
+    const float r00 = T[0], r01 = T[1], r02 = T[2], r10 = T[3], r11 = T[4], r12 = T[5], r20 = T[6], r21 = T[7], r22 = T[8];
+    const float t0 = T[9], t1 = T[10], t2 = T[11];
+    for (int i = tid; i < n1; i += 256) {
+        uint8_t st = 0;
+        const uint8_t fl = flags1[o + i];
+        if (fl & 1) {
+            const float X = world1[3 * (o + i)], Y = world1[3 * (o + i) + 1], Z = world1[3 * (o + i) + 2];
+            // Rcw * x3Dw + tcw as the small-matrix product computes it: float products summed in
+            // float, the translation added in double
+            const float xc = (float)((double)(r00 * X + r01 * Y + r02 * Z) + (double)t0);
+            const float yc = (float)((double)(r10 * X + r11 * Y + r12 * Z) + (double)t1);
+            const float zc = (float)((double)(r20 * X + r21 * Y + r22 * Z) + (double)t2);
+            const float invzc = (float)(1.0 / (double)zc);
+            const float u = a.fx * xc * invzc + a.cx;
+            const float v = a.fy * yc * invzc + a.cy;
+            const bool ok = !(invzc < 0) && u == u && v == v && !(u < a.min_x || u > a.max_x) && !(v < a.min_y || v > a.max_y);
+            if (ok) {
+                uv1[i] = make_float2(u, v);
+                ur1[i] = u - a.mbf * invzc;
+                st = (uint8_t)(1 | (fl & 2) | ((K1[i].octave & (ORB_MAX_LEVELS - 1)) << 2));
+            }
+        }
+        st1[i] = st;
+        bin1[i] = 0xFF;
+        best1[i] = MP_NONE;
+    }
+    __syncthreads();
+    const uint32_t total = block_excl_scan(s_cur, GRID_CELLS, s_tmp);
+    for (int c = tid; c < GRID_CELLS; c += 256) s_start[c] = (uint16_t)s_cur[c];
+    if (tid == 0) s_start[GRID_CELLS] = (uint16_t)total;
+    __syncthreads();
+    for (int i = tid; i < n2; i += 256) {
+        const int cell = cell2[i];
+        if (cell != 0xFFFF) sorted2[atomicAdd(&s_cur[cell], 1u)] = (uint16_t)i;
+    }
+    __syncthreads();
+
+    // Best candidate of last-frame keypoint i over the window, by the whole wave. use_occ: skip
+    // current keypoints that hold a point with observations (src/ORBmatcher.cc:1377-1379).
+    auto find_best = [&](int i, int st, bool use_occ) -> uint32_t {
+        const float2 p = uv1[i];
+        const float ur = ur1[i];
+        const int oct = st >> 2;
+        const float r = a.th * sf.v[oct];
+        const int lo = mode == 1 ? oct : mode == 2 ? 0 : oct - 1;           // octave range of GetFeaturesInArea's level test
+        const int hi = mode == 1 ? 255 : mode == 2 ? oct : oct + 1;
+        const int min_cx = max(0, (int)floorf((p.x - a.min_x - r) * a.inv_w));
+        const int max_cx = min(GRID_COLS - 1, (int)ceilf((p.x - a.min_x + r) * a.inv_w));
+        const int min_cy = max(0, (int)floorf((p.y - a.min_y - r) * a.inv_h));
+        const int max_cy = min(GRID_ROWS - 1, (int)ceilf((p.y - a.min_y + r) * a.inv_h));
+        if (min_cx >= GRID_COLS || max_cx < 0 || min_cy >= GRID_ROWS || max_cy < 0 || max_cx < min_cx || max_cy < min_cy) return MP_NONE;
+        const int ncy = max_cy - min_cy + 1, ncell = (max_cx - min_cx + 1) * ncy;
+        const uint32_t magic = s_magic[ncy];
+        const uint4* d1p = reinterpret_cast<const uint4*>(desc1 + (o + i) * 32);
+        const uint4 da = d1p[0], db = d1p[1];
+        unsigned long long best = ~0ull;                       // distance << 40 | cell << 20 | index
+        for (int c = lane; c < ncell; c += 64) {
+            const int qx = (int)(((uint32_t)c * magic) >> 20);
+            const int cell = (min_cx + qx) * GRID_ROWS + min_cy + (c - qx * ncy);
+            const int ke = s_start[cell + 1];
+            for (int k = s_start[cell]; k < ke; k++) {
+                const int i2 = sorted2[k];
+                const int o2 = oct2[i2];
+                if (o2 < lo || o2 > hi) continue;
+                const float2 q = pos2[i2];
+                if (!(fabsf(q.x - p.x) < r && fabsf(q.y - p.y) < r)) continue;
+                if (use_occ && occ2[i2]) continue;
+                const float u2 = ur2[i2];
+                if (u2 > 0 && fabsf(ur - u2) > r) continue;    // src/ORBmatcher.cc:1380-1385
+                const uint4* d2p = reinterpret_cast<const uint4*>(desc2 + (o + i2) * 32);
+                const uint4 x = d2p[0], y = d2p[1];
+                const unsigned dist = __popc(x.x ^ da.x) + __popc(x.y ^ da.y) + __popc(x.z ^ da.z) + __popc(x.w ^ da.w) +
+                                      __popc(y.x ^ db.x) + __popc(y.y ^ db.y) + __popc(y.z ^ db.z) + __popc(y.w ^ db.w);
+                if (dist >= 256) continue;                     // bestDist starts at 256 and only a smaller distance replaces it
+                const unsigned long long key = ((unsigned long long)dist << 40) | ((unsigned long long)cell << 20) | (unsigned)i2;
+                best = key < best ? key : best;
+            }
+        }
+        best = wave_min_u64(best);
+        return best == ~0ull ? MP_NONE : (uint32_t)((best >> 40) << 16) | (uint32_t)(best & 0xFFFF);
+    };
+
+    for (int i = wv; i < n1; i += 4) {
+        const int st = st1[i];                                 // wave-uniform
+        if (!(st & 1)) continue;
+        const uint32_t b = find_best(i, st, false);
+        if (lane == 0) best1[i] = b;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        // the reference's loop order; LDS operations of the one wave complete in issue order
+        const float factor = 1.0f / MT_HISTO;
+        int made = 0;
+        for (int i = 0; i < n1; i++) {
+            const int st = st1[i];
+            if (!(st & 1)) continue;
+            uint32_t b = best1[i];
+            if (b == MP_NONE) continue;
+            if (occ2[b & 0xFFFF]) {                            // taken by a point with observations meanwhile: search again
+                b = find_best(i, st, true);
+                if (b == MP_NONE) continue;
+            }
+            if ((b >> 16) > MP_TH_HIGH) continue;
+            const int i2 = (int)(b & 0xFFFF);
+            made++;
+            if (lane == 0) {
+                m2[i2] = i;                                    // a point without observations is simply overwritten
+                occ2[i2] = (uint8_t)((st >> 1) & 1);
+                taken1[i] = (uint16_t)i2;
+                if (a.check_orientation) {
+                    float rot = K1[i].angle - K2[i2].angle;
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == MT_HISTO) bin = 0;
+                    bin1[i] = (uint8_t)bin;
+                    s_hist[bin]++;
+                }
+            }
+        }
+        if (lane == 0) s_made = made;
+    }
+    __syncthreads();                                           // wave 0's stores to m2 are complete and visible to the workgroup
+    int bad = 0;
+    if (a.check_orientation) {
+        // ComputeThreeMaxima (src/ORBmatcher.cc:1566-1607); every assignment counts, overwritten ones too
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < MT_HISTO; i++) {
+            const int s = s_hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = tid; i < n1; i += 256) {
+            const int b = bin1[i];
+            if (b != 0xFF && b != ind1 && b != ind2 && b != ind3) { m2[taken1[i]] = -1; bad++; }   // src/ORBmatcher.cc:1430-1441
+        }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) bad += __shfl_xor(bad, s, 64);
+    if (lane == 0) s_tmp[wv] = (uint32_t)bad;
+    __syncthreads();
+    if (tid == 0) nmatches_out[f] = s_made - (int)(s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3]);
+}

@@ -1006,6 +1006,111 @@ int orbhip_search_for_initialization(orbhip_extractor* e, const orbhip_keypoint*
     return ORBHIP_OK;
 }
 
+int orbhip_projection_level_mode(const float* Tcw_cur, const float* Tcw_last, float mb, int mono) {
+    if (!Tcw_cur || !Tcw_last) return ORBHIP_ERR_ARG;
+    // twc = -Rcw^T tcw, tlc = Rlw twc + tlw (src/ORBmatcher.cc:1330-1335): CV_32F matrix products,
+    // accumulated in double and stored as float
+    float twc[3];
+    for (int r = 0; r < 3; r++) {
+        double acc = 0;
+        for (int k = 0; k < 3; k++) acc += (double)Tcw_cur[3 * k + r] * (double)Tcw_cur[9 + k];
+        twc[r] = (float)(-acc);
+    }
+    double acc = 0;
+    for (int k = 0; k < 3; k++) acc += (double)Tcw_last[6 + k] * (double)twc[k];
+    const float tlc_z = (float)(acc + (double)Tcw_last[11]);
+    if (mono) return 0;
+    if (tlc_z > mb) return 1;                                  // bForward
+    if (-tlc_z > mb) return 2;                                 // bBackward
+    return 0;
+}
+
+int orbhip_search_by_projection_batch_device(orbhip_extractor* e, int nframes, int cap,
+                                             const orbhip_keypoint* d_kp_last, const float* d_world_last,
+                                             const uint8_t* d_flags_last, const uint8_t* d_desc_last, const int* d_cnt_last,
+                                             const orbhip_keypoint* d_kp_cur, const uint8_t* d_desc_cur,
+                                             const float* d_uright_cur, const int* d_cnt_cur, const float* d_Tcw,
+                                             const int* d_level_mode, const orbhip_projection_params* prm,
+                                             int* d_match_cur, int* d_nmatches, void* stream) {
+    if (!e || nframes < 1 || cap < 1 || cap > 65534 || !d_kp_last || !d_world_last || !d_flags_last || !d_desc_last || !d_cnt_last ||
+        !d_kp_cur || !d_desc_cur || !d_cnt_cur || !d_Tcw || !prm || !d_match_cur || !d_nmatches ||
+        !(prm->bounds[1] > prm->bounds[0]) || !(prm->bounds[3] > prm->bounds[2]))
+        return ORBHIP_ERR_ARG;
+    const size_t lds = (size_t)MP_LDS_PER_KP * cap + 16;
+    if (lds > 160 * 1024 - 20 * 1024) { e->err = "too many keypoints per frame for the on-chip matcher state"; return ORBHIP_ERR_CAPACITY; }
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    if (lds > 40 * 1024)
+        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_proj), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProjArgs a;
+    a.fx = prm->fx; a.fy = prm->fy; a.cx = prm->cx; a.cy = prm->cy; a.mbf = prm->mbf;
+    a.min_x = prm->bounds[0]; a.max_x = prm->bounds[1]; a.min_y = prm->bounds[2]; a.max_y = prm->bounds[3];
+    a.inv_w = static_cast<float>(GRID_COLS) / (prm->bounds[1] - prm->bounds[0]);   // src/Frame.cc:128-129
+    a.inv_h = static_cast<float>(GRID_ROWS) / (prm->bounds[3] - prm->bounds[2]);
+    a.th = prm->th;
+    a.check_orientation = prm->check_orientation;
+    ScaleTab sf;
+    for (int l = 0; l < ORB_MAX_LEVELS; l++) sf.v[l] = e->sf[std::min(l, e->prm.nlevels - 1)];
+    hipLaunchKernelGGL(k_search_proj, dim3(nframes), dim3(256), lds, s, reinterpret_cast<const GridKp*>(d_kp_last), d_world_last,
+                       d_flags_last, d_desc_last, d_cnt_last, reinterpret_cast<const GridKp*>(d_kp_cur), d_desc_cur, d_uright_cur,
+                       d_cnt_cur, cap, d_Tcw, d_level_mode, a, sf, d_match_cur, d_nmatches);
+    HIP_TRY(e, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_search_by_projection(orbhip_extractor* e, const orbhip_keypoint* kp_last, const float* world_last,
+                                const uint8_t* flags_last, const uint8_t* desc_last, int n1,
+                                const orbhip_keypoint* kp_cur, const uint8_t* desc_cur, const float* uright_cur, int n2,
+                                const float* Tcw, int level_mode, const orbhip_projection_params* prm,
+                                int* match_cur, int* nmatches) {
+    if (!e || n1 < 0 || n2 < 0 || !Tcw || !prm || !nmatches) return ORBHIP_ERR_ARG;
+    if (n2 > 0 && !match_cur) return ORBHIP_ERR_ARG;
+    for (int i = 0; i < n2; i++) match_cur[i] = -1;
+    if (n1 == 0 || n2 == 0) { *nmatches = 0; return ORBHIP_OK; }
+    if (!kp_last || !world_last || !flags_last || !desc_last || !kp_cur || !desc_cur) return ORBHIP_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    const int cap = std::max(n1, n2);
+    auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
+    const size_t kpb = up((size_t)cap * sizeof(orbhip_keypoint)), db = up((size_t)cap * 32), wb = up((size_t)cap * 12);
+    const size_t fb = up((size_t)cap), ub = up((size_t)cap * 4), mb = up((size_t)cap * 4);
+    const size_t need = 128 + 2 * kpb + 2 * db + wb + fb + ub + mb;
+    if (need > e->d_st_tmp_bytes) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        dfree(e->d_st_tmp);
+        HIP_TRY(e, hipMalloc(&e->d_st_tmp, need));
+        e->d_st_tmp_bytes = need;
+    }
+    uint8_t* p = e->d_st_tmp;
+    int* d_cnt = reinterpret_cast<int*>(p);                     // [0] n1, [1] n2, [2] matches, [3] level mode
+    float* d_T = reinterpret_cast<float*>(p + 64); p += 128;
+    orbhip_keypoint* d_k1 = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
+    orbhip_keypoint* d_k2 = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
+    uint8_t* d_d1 = p; p += db;
+    uint8_t* d_d2 = p; p += db;
+    float* d_w = reinterpret_cast<float*>(p); p += wb;
+    uint8_t* d_f = p; p += fb;
+    float* d_u = reinterpret_cast<float*>(p); p += ub;
+    int* d_m = reinterpret_cast<int*>(p);
+    const int cnt[4] = {n1, n2, 0, level_mode};
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(d_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_T, Tcw, 12 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_k1, kp_last, (size_t)n1 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_d1, desc_last, (size_t)n1 * 32, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_w, world_last, (size_t)n1 * 12, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_f, flags_last, (size_t)n1, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_k2, kp_cur, (size_t)n2 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_d2, desc_cur, (size_t)n2 * 32, hipMemcpyHostToDevice));
+    if (uright_cur) HIP_TRY(e, hipMemcpy(d_u, uright_cur, (size_t)n2 * 4, hipMemcpyHostToDevice));
+    int rc = orbhip_search_by_projection_batch_device(e, 1, cap, d_k1, d_w, d_f, d_d1, d_cnt, d_k2, d_d2, uright_cur ? d_u : nullptr,
+                                                      d_cnt + 1, d_T, d_cnt + 3, prm, d_m, d_cnt + 2, nullptr);
+    if (rc) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(match_cur, d_m, (size_t)n2 * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(nmatches, d_cnt + 2, sizeof(int), hipMemcpyDeviceToHost));
+    return ORBHIP_OK;
+}
+
 const char* orbhip_strerror(int code) {
     switch (code) {
         case ORBHIP_OK: return "ok";

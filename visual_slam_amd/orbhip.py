@@ -34,6 +34,7 @@ EXPORTS = [
     "orbhip_extract_color", "orbhip_extract_batch_device_color",
     "orbhip_image_bounds", "orbhip_undistort_grid", "orbhip_undistort_grid_batch_device",
     "orbhip_search_for_initialization", "orbhip_search_for_initialization_batch_device",
+    "orbhip_search_by_projection", "orbhip_search_by_projection_batch_device", "orbhip_projection_level_mode",
 ]
 
 
@@ -95,6 +96,10 @@ def lib():
         L.orbhip_search_for_initialization.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_int, vp, ip]
         L.orbhip_search_for_initialization_batch_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int,
                                                                     C.c_float, C.c_int, vp, vp, vp]
+        L.orbhip_search_by_projection.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, ip]
+        L.orbhip_search_by_projection_batch_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                                               vp, vp, vp]
+        L.orbhip_projection_level_mode.argtypes = [vp, vp, C.c_float, C.c_int]
         L.orbhip_stereo_match.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, ip]
         L.orbhip_stereo_match_batch_device.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float,
                                                        vp, vp, vp, vp]
@@ -147,6 +152,44 @@ def SearchForInitialization(ex, kp1, desc1, kp2, desc2, bounds, prev_matched, wi
                                                      _ptr(np.ascontiguousarray(bounds, np.float32)), _ptr(prev), int(window),
                                                      float(nnratio), int(bool(check_orientation)), _ptr(m12), C.byref(n)))
     return m12[:len(kp1)], prev, n.value
+
+
+class ProjectionParams(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("mbf", C.c_float),
+                ("bounds", C.c_float * 4), ("th", C.c_float), ("check_orientation", C.c_int)]
+
+
+def projection_params(cam4, mbf, bounds, th, check_orientation=True):
+    b = [float(v) for v in bounds]
+    return ProjectionParams(float(cam4[0]), float(cam4[1]), float(cam4[2]), float(cam4[3]), float(mbf),
+                            (C.c_float * 4)(*b), float(th), int(bool(check_orientation)))
+
+
+def ProjectionLevelMode(Tcw_cur, Tcw_last, mb, mono):
+    """bForward / bBackward of SearchByProjection(CurrentFrame, LastFrame) (reference src/ORBmatcher.cc:1330-1337):
+    0 neither, 1 forward, 2 backward. Poses as 12 floats: R row-major, then t."""
+    a = np.ascontiguousarray(Tcw_cur, np.float32).reshape(12); b = np.ascontiguousarray(Tcw_last, np.float32).reshape(12)
+    return lib().orbhip_projection_level_mode(_ptr(a), _ptr(b), float(mb), int(bool(mono)))
+
+
+def SearchByProjection(ex, kp_last, world_last, flags_last, desc_last, kp_cur, desc_cur, uright_cur, Tcw, cam4, mbf, bounds, th,
+                       level_mode=0, check_orientation=True):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (reference src/ORBmatcher.cc:1324-1445)
+    on the device. Returns (match_cur, nmatches): match_cur[i2] = index of the last-frame keypoint whose
+    map point current keypoint i2 received, or -1."""
+    kp_last = np.ascontiguousarray(kp_last, KP_DTYPE); kp_cur = np.ascontiguousarray(kp_cur, KP_DTYPE)
+    world = np.ascontiguousarray(world_last, np.float32).reshape(-1, 3)
+    flags = np.ascontiguousarray(flags_last, np.uint8)
+    d1 = np.ascontiguousarray(desc_last, np.uint8); d2 = np.ascontiguousarray(desc_cur, np.uint8)
+    ur = None if uright_cur is None else np.ascontiguousarray(uright_cur, np.float32)
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(12)
+    prm = projection_params(cam4, mbf, bounds, th, check_orientation)
+    m = np.full(max(len(kp_cur), 1), -1, np.int32)
+    n = C.c_int(0)
+    ex._check(lib().orbhip_search_by_projection(ex._h, _ptr(kp_last), _ptr(world), _ptr(flags), _ptr(d1), len(kp_last),
+                                                _ptr(kp_cur), _ptr(d2), None if ur is None else _ptr(ur), len(kp_cur),
+                                                _ptr(T), int(level_mode), C.byref(prm), _ptr(m), C.byref(n)))
+    return m[:len(kp_cur)], n.value
 
 
 def ComputeStereoMatches(left, right, kp_l, desc_l, kp_r, desc_r, mb, mbf):
