@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Throughput of the device matchers on a batch of frame pairs that stays in device memory:
+extraction of both frames, undistortion, then ORBmatcher::SearchByProjection(CurrentFrame, LastFrame)
+for every pair in one launch. Prints one JSON line; the CPU figure is the oracle's restatement of the
+same function on the same pairs (one thread).
+
+Usage: python tools/match_bench.py [--pairs 256] [--width 1241 --height 376] [--steps 5]
+"""
+import argparse
+import json
+import pathlib
+import sys
+import time
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from visual_slam_amd import orbhip, synth  # noqa: E402
+
+KITTI = (718.856, 718.856, 607.1928, 185.2157, 0.0, 0.0, 0.0, 0.0, 0.0)
+Z = 6.0
+
+
+def shifted(img, dx, dy):
+    out = img.copy()
+    h, w = img.shape
+    out[max(dy, 0):h + min(dy, 0), max(dx, 0):w + min(dx, 0)] = img[max(-dy, 0):h + min(-dy, 0), max(-dx, 0):w + min(-dx, 0)]
+    return out
+
+
+def main():
+    import torch
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=256)
+    ap.add_argument("--width", type=int, default=1241)
+    ap.add_argument("--height", type=int, default=376)
+    ap.add_argument("--nfeatures", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--th", type=float, default=15.0)
+    ap.add_argument("--cpu-pairs", type=int, default=16)
+    ap.add_argument("--observed", type=float, default=0.8, help="fraction of map points with observations")
+    args = ap.parse_args()
+    n, w, h = args.pairs, args.width, args.height
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    last = np.stack([synth.frame("blocks", w, h, 900 + i) for i in range(n)])
+    motion = [((i * 7) % 23 - 11, (i * 5) % 13 - 6) for i in range(n)]
+    cur = np.stack([shifted(last[i], *motion[i]) for i in range(n)])
+    ex = orbhip.ORBextractor(args.nfeatures, 1.2, 8, 20, 7)
+    cap = ex.max_keypoints()
+    fx, fy, cx, cy = KITTI[:4]
+    bounds = orbhip.ComputeImageBounds(KITTI, w, h)
+    cam = np.array(KITTI, np.float32)
+    with torch.cuda.stream(stream):
+        dl = torch.from_numpy(last).to(dev); dc = torch.from_numpy(cur).to(dev)
+        mk = lambda: (torch.zeros((n, cap, 7), dtype=torch.float32, device=dev), torch.zeros((n, cap, 32), dtype=torch.uint8, device=dev),
+                      torch.zeros((n,), dtype=torch.int32, device=dev))
+        (k1, d1, c1), (k2, d2, c2) = mk(), mk()
+        u1 = torch.zeros_like(k1); u2 = torch.zeros_like(k2)
+        gs = torch.zeros((n, orbhip.GRID_CELLS + 1), dtype=torch.int32, device=dev)
+        gi = torch.zeros((n, cap), dtype=torch.int32, device=dev)
+        match = torch.zeros((n, cap), dtype=torch.int32, device=dev)
+        nm = torch.zeros((n,), dtype=torch.int32, device=dev)
+    stream.synchronize()
+    sp = stream.cuda_stream
+    L = orbhip.lib()
+    cam_c = orbhip._cam(cam); b_c = np.ascontiguousarray(bounds, np.float32)
+    ex.extract_batch_device(dl.data_ptr(), n, w, h, w, w * h, k1.data_ptr(), d1.data_ptr(), c1.data_ptr(), cap, stream=sp)
+    ex._check(L.orbhip_undistort_grid_batch_device(ex._h, n, k1.data_ptr(), c1.data_ptr(), cap, orbhip._ptr(cam_c), orbhip._ptr(b_c),
+                                                   u1.data_ptr(), gs.data_ptr(), gi.data_ptr(), sp))
+    ex.extract_batch_device(dc.data_ptr(), n, w, h, w, w * h, k2.data_ptr(), d2.data_ptr(), c2.data_ptr(), cap, stream=sp)
+    ex._check(L.orbhip_undistort_grid_batch_device(ex._h, n, k2.data_ptr(), c2.data_ptr(), cap, orbhip._ptr(cam_c), orbhip._ptr(b_c),
+                                                   u2.data_ptr(), gs.data_ptr(), gi.data_ptr(), sp))
+    stream.synchronize()
+    # map points: the last frame's keypoints on the plane z = Z; the current pose explains the image motion
+    hu1 = u1.cpu().numpy()
+    world = np.stack([(hu1[..., 0] - cx) * Z / fx, (hu1[..., 1] - cy) * Z / fy, np.full(hu1.shape[:2], Z)], axis=2).astype(np.float32)
+    rng = np.random.default_rng(11)
+    flags = ((rng.random((n, cap)) < 0.85).astype(np.uint8) | ((rng.random((n, cap)) < args.observed).astype(np.uint8) << 1))
+    Tcw = np.stack([np.concatenate([np.eye(3).ravel(), [dx * Z / fx, dy * Z / fy, 0.0]]) for dx, dy in motion]).astype(np.float32)
+    with torch.cuda.stream(stream):
+        dw = torch.from_numpy(world).to(dev); df = torch.from_numpy(flags).to(dev); dT = torch.from_numpy(Tcw).to(dev)
+    stream.synchronize()
+    prm = orbhip.projection_params(KITTI[:4], 0.5 * fx, bounds, args.th, True)
+
+    def step():
+        orbhip.search_by_projection_batch_device(ex, n, cap, u1.data_ptr(), dw.data_ptr(), df.data_ptr(), d1.data_ptr(), c1.data_ptr(),
+                                                 u2.data_ptr(), d2.data_ptr(), None, c2.data_ptr(), dT.data_ptr(), None, prm,
+                                                 match.data_ptr(), nm.data_ptr(), stream=sp)
+    step(); stream.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        e0.record(stream)
+        for _ in range(args.steps):
+            step()
+        e1.record(stream)
+    stream.synchronize()
+    ms = e0.elapsed_time(e1) / args.steps
+    hm, hn = match.cpu().numpy(), nm.cpu().numpy()
+    out = {"op": "SearchByProjection(CurrentFrame, LastFrame)", "pairs": n, "image": [w, h], "th": args.th,
+           "ms_per_batch": round(ms, 3), "pairs_per_s": round(n / ms * 1e3, 1), "mean_matches": float(hn.mean())}
+    # oracle on the first pairs: parity and the CPU time
+    try:
+        from oracle import orb_oracle as O
+        hu2, hd1, hd2 = u2.cpu().numpy(), d1.cpu().numpy(), d2.cpu().numpy()
+        hc1, hc2 = c1.cpu().numpy(), c2.cpu().numpy()
+        sf = np.array(ex.GetScaleFactors(), np.float32)
+        m = min(args.cpu_pairs, n)
+        ok, t = True, 0.0
+        for i in range(m):
+            a1 = np.zeros(hc1[i], orbhip.KP_DTYPE); a1[:] = hu1[i, :hc1[i]].view(orbhip.KP_DTYPE).reshape(-1)
+            a2 = np.zeros(hc2[i], orbhip.KP_DTYPE); a2[:] = hu2[i, :hc2[i]].view(orbhip.KP_DTYPE).reshape(-1)
+            t0 = time.perf_counter()
+            om, on = O.search_by_projection(a1, world[i, :hc1[i]], flags[i, :hc1[i]], hd1[i, :hc1[i]], a2, hd2[i, :hc2[i]], None, Tcw[i],
+                                            KITTI[:4], 0.5 * fx, bounds, sf, args.th, 0, True)
+            t += time.perf_counter() - t0
+            ok = ok and on == hn[i] and np.array_equal(om, hm[i, :hc2[i]])
+        out["oracle_parity_first_pairs"] = bool(ok)
+        out["cpu_oracle_pairs_per_s_one_thread"] = round(m / t, 1)
+    except ImportError:
+        pass
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -171,18 +171,46 @@ __global__ __launch_bounds__(64) void k_search_init(const GridKp* __restrict__ k
 //
 // The reference loop over the last frame's keypoints is sequential only through one rule: a
 // current keypoint that already holds a point with observations is skipped. The kernel therefore
-// splits the work. First every last-frame keypoint finds, in parallel, its best candidate with that
-// rule ignored (one wave per keypoint, lanes over the grid cells of the window; the current
+// splits the work. First every last-frame keypoint finds, in parallel, its best few candidates with
+// that rule ignored (one wave per keypoint, lanes over the grid cells of the window; the current
 // keypoints are bucketed by grid cell in LDS first). Then one wave walks the keypoints in order:
-// if the best candidate is still free it is the reference's answer (the minimum over a superset
-// that lies in the subset), otherwise the search is repeated with the rule applied. The traversal
+// the first listed candidate that is still free is the reference's answer (the minimum over a
+// superset that lies in the subset); only when the whole list is taken and may be incomplete is the
+// search repeated with the rule applied. The traversal
 // order of the reference (cells by column then row, indices ascending inside a cell, first of equal
 // distances wins) is the minimum over (distance, cell, index).
-// One workgroup (4 waves) per frame pair.
+// One workgroup (MP_THREADS / 64 waves) per frame pair: the searches wait on descriptor loads, so
+// many waves per pair hide that latency.
 // ------------------------------------------------------------------------------------------------
 #define MP_TH_HIGH 100        // ORBmatcher::TH_HIGH (src/ORBmatcher.cc:38)
-#define MP_LDS_PER_KP 38      // dynamic LDS bytes per keypoint slot (see the carve-up below)
-#define MP_NONE 0xFFFFFFFFu
+#define MP_LDS_PER_KP 50      // dynamic LDS bytes per keypoint slot (see the carve-up below)
+#define MP_LIST 4             // candidates kept per last-frame keypoint
+#define MP_END 0xFFFFFFFEu    // list terminator: there are no further acceptable candidates
+#define MP_NONE 0xFFFFFFFFu    // no candidate / list terminator: further candidates are unknown
+#define MP_THREADS 1024
+#define MP_WAVES (MP_THREADS / 64)
+
+// Exclusive prefix sum of a[0..n) in place by the whole workgroup; returns the total.
+__device__ __forceinline__ uint32_t mp_block_excl_scan(uint32_t* a, int n, uint32_t* s_part) {
+    const int tid = threadIdx.x;
+    const int chunk = (n + MP_THREADS - 1) / MP_THREADS;
+    const int lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+    uint32_t s = 0;
+    for (int i = lo; i < hi; i++) s += a[i];
+    const uint32_t inc = wave_scan_incl(s);
+    if ((tid & 63) == 63) s_part[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < MP_WAVES; w++) {
+        if (w < (tid >> 6)) off += s_part[w];
+        total += s_part[w];
+    }
+    uint32_t run = off + inc - s;
+    for (int i = lo; i < hi; i++) { const uint32_t v = a[i]; a[i] = run; run += v; }
+    __syncthreads();
+    return total;
+}
 
 struct ScaleTab { float v[ORB_MAX_LEVELS]; };                 // mvScaleFactors
 
@@ -193,7 +221,7 @@ struct ProjArgs {
     int check_orientation;
 };
 
-__global__ __launch_bounds__(256) void k_search_proj(const GridKp* __restrict__ kp1, const float* __restrict__ world1,
+__global__ __launch_bounds__(MP_THREADS) void k_search_proj(const GridKp* __restrict__ kp1, const float* __restrict__ world1,
                                                      const uint8_t* __restrict__ flags1, const uint8_t* __restrict__ desc1,
                                                      const int* __restrict__ cnt1, const GridKp* __restrict__ kp2,
                                                      const uint8_t* __restrict__ desc2, const float* __restrict__ uright2,
@@ -201,12 +229,12 @@ __global__ __launch_bounds__(256) void k_search_proj(const GridKp* __restrict__ 
                                                      const int* __restrict__ level_mode, ProjArgs a, ScaleTab sf,
                                                      int* __restrict__ match2, int* __restrict__ nmatches_out) {
     extern __shared__ __align__(16) uint8_t mp_smem[];
-    float2* pos2 = reinterpret_cast<float2*>(mp_smem);                       // current keypoints: position
+    uint32_t* list1 = reinterpret_cast<uint32_t*>(mp_smem);                  // last: MP_LIST x (distance << 16 | current index), best first, occupancy ignored
+    float2* pos2 = reinterpret_cast<float2*>(list1 + MP_LIST * (size_t)cap);  // current keypoints: position
     float2* uv1 = pos2 + cap;                                                // last keypoints: projection (u, v)
     float* ur2 = reinterpret_cast<float*>(uv1 + cap);                        // current: mvuRight
     float* ur1 = ur2 + cap;                                                  // last: u - mbf / z
-    uint32_t* best1 = reinterpret_cast<uint32_t*>(ur1 + cap);                // last: distance << 16 | current index, occupancy ignored
-    uint16_t* sorted2 = reinterpret_cast<uint16_t*>(best1 + cap);            // current indices bucketed by grid cell
+    uint16_t* sorted2 = reinterpret_cast<uint16_t*>(ur1 + cap);              // current indices bucketed by grid cell
     uint16_t* cell2 = sorted2 + cap;                                         // current: grid cell, 0xFFFF = outside
     uint16_t* taken1 = cell2 + cap;                                          // last: the current keypoint it was assigned to
     uint8_t* oct2 = reinterpret_cast<uint8_t*>(taken1 + cap);                // current: octave
@@ -216,7 +244,7 @@ __global__ __launch_bounds__(256) void k_search_proj(const GridKp* __restrict__ 
     __shared__ uint32_t s_cur[GRID_CELLS];                                   // histogram, then running cursor
     __shared__ uint16_t s_start[GRID_CELLS + 2];
     __shared__ uint32_t s_magic[GRID_ROWS + 1];
-    __shared__ uint32_t s_tmp[4];
+    __shared__ uint32_t s_tmp[MP_WAVES];
     __shared__ int s_hist[MT_HISTO];
     __shared__ int s_made;
     const int tid = threadIdx.x, lane = tid & 63, f = blockIdx.x;
@@ -229,12 +257,12 @@ __global__ __launch_bounds__(256) void k_search_proj(const GridKp* __restrict__ 
     const float* T = Tcw + 12 * (size_t)f;
     int* m2 = match2 + o;
 
-    for (int c = tid; c < GRID_CELLS; c += 256) s_cur[c] = 0;
+    for (int c = tid; c < GRID_CELLS; c += MP_THREADS) s_cur[c] = 0;
     if (tid >= 1 && tid <= GRID_ROWS) s_magic[tid] = ((1u << 20) + tid - 1) / tid;   // n / d == n * magic >> 20 for n * d < 2^20
     if (tid < MT_HISTO) s_hist[tid] = 0;
     if (tid == 0) s_made = 0;
     __syncthreads();
-    for (int i = tid; i < n2; i += 256) {
+    for (int i = tid; i < n2; i += MP_THREADS) {
         const GridKp k = K2[i];
         const int cell = grid_cell(k.x, k.y, a.min_x, a.min_y, a.inv_w, a.inv_h);
         pos2[i] = make_float2(k.x, k.y);
@@ -248,7 +276,7 @@ __global__ __launch_bounds__(256) void k_search_proj(const GridKp* __restrict__ 
     // projections of the last frame's map points (src/ORBmatcher.cc:1343-1361)
     const float r00 = T[0], r01 = T[1], r02 = T[2], r10 = T[3], r11 = T[4], r12 = T[5], r20 = T[6], r21 = T[7], r22 = T[8];
     const float t0 = T[9], t1 = T[10], t2 = T[11];
-    for (int i = tid; i < n1; i += 256) {
+    for (int i = tid; i < n1; i += MP_THREADS) {
         uint8_t st = 0;
         const uint8_t fl = flags1[o + i];
         if (fl & 1) {
@@ -270,22 +298,26 @@ __global__ __launch_bounds__(256) void k_search_proj(const GridKp* __restrict__ 
         }
         st1[i] = st;
         bin1[i] = 0xFF;
-        best1[i] = MP_NONE;
+        list1[MP_LIST * i] = MP_END;
     }
     __syncthreads();
-    const uint32_t total = block_excl_scan(s_cur, GRID_CELLS, s_tmp);
-    for (int c = tid; c < GRID_CELLS; c += 256) s_start[c] = (uint16_t)s_cur[c];
+    const uint32_t total = mp_block_excl_scan(s_cur, GRID_CELLS, s_tmp);
+    for (int c = tid; c < GRID_CELLS; c += MP_THREADS) s_start[c] = (uint16_t)s_cur[c];
     if (tid == 0) s_start[GRID_CELLS] = (uint16_t)total;
     __syncthreads();
-    for (int i = tid; i < n2; i += 256) {
+    for (int i = tid; i < n2; i += MP_THREADS) {
         const int cell = cell2[i];
         if (cell != 0xFFFF) sorted2[atomicAdd(&s_cur[cell], 1u)] = (uint16_t)i;
     }
     __syncthreads();
 
-    // Best candidate of last-frame keypoint i over the window, by the whole wave. use_occ: skip
-    // current keypoints that hold a point with observations (src/ORBmatcher.cc:1377-1379).
-    auto find_best = [&](int i, int st, bool use_occ) -> uint32_t {
+    // The best candidates of last-frame keypoint i over the window, by the whole wave: e[0..return)
+    // in the reference's order of preference, then a terminator (MP_END: nothing acceptable follows,
+    // MP_NONE: unknown) unless all MP_LIST slots are used. use_occ: skip current keypoints that hold
+    // a point with observations (src/ORBmatcher.cc:1377-1379).
+    auto find_cands = [&](int i, int st, bool use_occ, uint32_t (&e)[MP_LIST]) {
+#pragma unroll
+        for (int r = 0; r < MP_LIST; r++) e[r] = MP_END;
         const float2 p = uv1[i];
         const float ur = ur1[i];
         const int oct = st >> 2;
@@ -296,12 +328,14 @@ __global__ __launch_bounds__(256) void k_search_proj(const GridKp* __restrict__ 
         const int max_cx = min(GRID_COLS - 1, (int)ceilf((p.x - a.min_x + r) * a.inv_w));
         const int min_cy = max(0, (int)floorf((p.y - a.min_y - r) * a.inv_h));
         const int max_cy = min(GRID_ROWS - 1, (int)ceilf((p.y - a.min_y + r) * a.inv_h));
-        if (min_cx >= GRID_COLS || max_cx < 0 || min_cy >= GRID_ROWS || max_cy < 0 || max_cx < min_cx || max_cy < min_cy) return MP_NONE;
+        if (min_cx >= GRID_COLS || max_cx < 0 || min_cy >= GRID_ROWS || max_cy < 0 || max_cx < min_cx || max_cy < min_cy) return;
         const int ncy = max_cy - min_cy + 1, ncell = (max_cx - min_cx + 1) * ncy;
         const uint32_t magic = s_magic[ncy];
         const uint4* d1p = reinterpret_cast<const uint4*>(desc1 + (o + i) * 32);
         const uint4 da = d1p[0], db = d1p[1];
-        unsigned long long best = ~0ull;                       // distance << 40 | cell << 20 | index
+        // per lane: its two smallest keys  distance << 40 | cell << 20 | index  and how many it saw
+        unsigned long long b1 = ~0ull, b2 = ~0ull;
+        int seen = 0;
         for (int c = lane; c < ncell; c += 64) {
             const int qx = (int)(((uint32_t)c * magic) >> 20);
             const int cell = (min_cx + qx) * GRID_ROWS + min_cy + (c - qx * ncy);
@@ -319,50 +353,60 @@ __global__ __launch_bounds__(256) void k_search_proj(const GridKp* __restrict__ 
                 const uint4 x = d2p[0], y = d2p[1];
                 const unsigned dist = __popc(x.x ^ da.x) + __popc(x.y ^ da.y) + __popc(x.z ^ da.z) + __popc(x.w ^ da.w) +
                                       __popc(y.x ^ db.x) + __popc(y.y ^ db.y) + __popc(y.z ^ db.z) + __popc(y.w ^ db.w);
-                if (dist >= 256) continue;                     // bestDist starts at 256 and only a smaller distance replaces it
+                if (dist > MP_TH_HIGH) continue;               // can never be accepted (src/ORBmatcher.cc:1396)
                 const unsigned long long key = ((unsigned long long)dist << 40) | ((unsigned long long)cell << 20) | (unsigned)i2;
-                best = key < best ? key : best;
+                seen++;
+                if (key < b1) { b2 = b1; b1 = key; }
+                else if (key < b2) b2 = key;
             }
         }
-        best = wave_min_u64(best);
-        return best == ~0ull ? MP_NONE : (uint32_t)((best >> 40) << 16) | (uint32_t)(best & 0xFFFF);
+        // the wave's smallest keys one after the other; a lane that has handed out both keys it kept
+        // and saw more ends the list, because its third key might come next
+        int used = 0;
+#pragma unroll
+        for (int r = 0; r < MP_LIST; r++) {
+            const unsigned long long m = wave_min_u64(b1);
+            if (m == ~0ull) break;                             // e[r] stays MP_END
+            e[r] = (uint32_t)((m >> 40) << 16) | (uint32_t)(m & 0xFFFF);
+            bool dry = false;
+            if (b1 == m) { used++; b1 = b2; b2 = ~0ull; dry = used == 2 && seen > 2; }
+            if (__ballot(dry)) { if (r + 1 < MP_LIST) e[r + 1] = MP_NONE; break; }
+        }
     };
 
-    for (int i = wv; i < n1; i += 4) {
-        const int st = st1[i];                                 // wave-uniform
+    for (int i = wv; i < n1; i += MP_WAVES) {
+        const int st = __builtin_amdgcn_readfirstlane((int)st1[i]);
         if (!(st & 1)) continue;
-        const uint32_t b = find_best(i, st, false);
-        if (lane == 0) best1[i] = b;
+        uint32_t e[MP_LIST];
+        find_cands(i, st, false, e);
+        if (lane == 0) *reinterpret_cast<uint4*>(&list1[MP_LIST * i]) = make_uint4(e[0], e[1], e[2], e[3]);
     }
     __syncthreads();
     if (wv == 0) {
         // the reference's loop order; LDS operations of the one wave complete in issue order
-        const float factor = 1.0f / MT_HISTO;
         int made = 0;
         for (int i = 0; i < n1; i++) {
-            const int st = st1[i];
+            const int st = __builtin_amdgcn_readfirstlane((int)st1[i]);       // the same in every lane: scalar control flow
             if (!(st & 1)) continue;
-            uint32_t b = best1[i];
-            if (b == MP_NONE) continue;
-            if (occ2[b & 0xFFFF]) {                            // taken by a point with observations meanwhile: search again
-                b = find_best(i, st, true);
-                if (b == MP_NONE) continue;
+            uint32_t b = MP_NONE;                              // MP_NONE after the walk: the list did not decide
+            for (int r = 0; r < MP_LIST; r++) {
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)list1[MP_LIST * i + r]);
+                if (c >= MP_END) { b = c; break; }
+                if (!__builtin_amdgcn_readfirstlane((int)occ2[c & 0xFFFF])) { b = c; break; }   // still free: the reference's choice
             }
-            if ((b >> 16) > MP_TH_HIGH) continue;
+            if (b == MP_NONE) {                                // every listed candidate was taken meanwhile: search again
+                uint32_t e[MP_LIST];
+                find_cands(i, st, true, e);
+                b = e[0];
+            }
+            if (b >= MP_END) continue;                         // bestDist > TH_HIGH or no candidate
             const int i2 = (int)(b & 0xFFFF);
             made++;
             if (lane == 0) {
                 m2[i2] = i;                                    // a point without observations is simply overwritten
                 occ2[i2] = (uint8_t)((st >> 1) & 1);
                 taken1[i] = (uint16_t)i2;
-                if (a.check_orientation) {
-                    float rot = K1[i].angle - K2[i2].angle;
-                    if (rot < 0.0f) rot += 360.0f;
-                    int bin = (int)roundf(rot * factor);
-                    if (bin == MT_HISTO) bin = 0;
-                    bin1[i] = (uint8_t)bin;
-                    s_hist[bin]++;
-                }
+                bin1[i] = 0xFE;                                // matched; its rotation bin is filled in below, in parallel
             }
         }
         if (lane == 0) s_made = made;
@@ -370,6 +414,18 @@ __global__ __launch_bounds__(256) void k_search_proj(const GridKp* __restrict__ 
     __syncthreads();                                           // wave 0's stores to m2 are complete and visible to the workgroup
     int bad = 0;
     if (a.check_orientation) {
+        // rotation histogram of every assignment made (src/ORBmatcher.cc:1409-1418)
+        const float factor = 1.0f / MT_HISTO;
+        for (int i = tid; i < n1; i += MP_THREADS) {
+            if (bin1[i] != 0xFE) continue;
+            float rot = K1[i].angle - K2[taken1[i]].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == MT_HISTO) bin = 0;
+            bin1[i] = (uint8_t)bin;
+            atomicAdd(&s_hist[bin], 1);
+        }
+        __syncthreads();
         // ComputeThreeMaxima (src/ORBmatcher.cc:1566-1607); every assignment counts, overwritten ones too
         int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
         for (int i = 0; i < MT_HISTO; i++) {
@@ -380,7 +436,7 @@ __global__ __launch_bounds__(256) void k_search_proj(const GridKp* __restrict__ 
         }
         if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
         else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
-        for (int i = tid; i < n1; i += 256) {
+        for (int i = tid; i < n1; i += MP_THREADS) {
             const int b = bin1[i];
             if (b != 0xFF && b != ind1 && b != ind2 && b != ind3) { m2[taken1[i]] = -1; bad++; }   // src/ORBmatcher.cc:1430-1441
         }
@@ -389,5 +445,9 @@ __global__ __launch_bounds__(256) void k_search_proj(const GridKp* __restrict__ 
     for (int s = 32; s > 0; s >>= 1) bad += __shfl_xor(bad, s, 64);
     if (lane == 0) s_tmp[wv] = (uint32_t)bad;
     __syncthreads();
-    if (tid == 0) nmatches_out[f] = s_made - (int)(s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3]);
+    if (tid == 0) {
+        int bad_all = 0;
+        for (int w = 0; w < MP_WAVES; w++) bad_all += (int)s_tmp[w];
+        nmatches_out[f] = s_made - bad_all;
+    }
 }

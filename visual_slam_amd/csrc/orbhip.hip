@@ -1051,7 +1051,7 @@ int orbhip_search_by_projection_batch_device(orbhip_extractor* e, int nframes, i
     a.check_orientation = prm->check_orientation;
     ScaleTab sf;
     for (int l = 0; l < ORB_MAX_LEVELS; l++) sf.v[l] = e->sf[std::min(l, e->prm.nlevels - 1)];
-    hipLaunchKernelGGL(k_search_proj, dim3(nframes), dim3(256), lds, s, reinterpret_cast<const GridKp*>(d_kp_last), d_world_last,
+    hipLaunchKernelGGL(k_search_proj, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const GridKp*>(d_kp_last), d_world_last,
                        d_flags_last, d_desc_last, d_cnt_last, reinterpret_cast<const GridKp*>(d_kp_cur), d_desc_cur, d_uright_cur,
                        d_cnt_cur, cap, d_Tcw, d_level_mode, a, sf, d_match_cur, d_nmatches);
     HIP_TRY(e, hipGetLastError());

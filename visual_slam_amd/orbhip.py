@@ -192,6 +192,16 @@ def SearchByProjection(ex, kp_last, world_last, flags_last, desc_last, kp_cur, d
     return m[:len(kp_cur)], n.value
 
 
+def search_by_projection_batch_device(ex, nframes, cap, d_kp_last, d_world_last, d_flags_last, d_desc_last, d_cnt_last,
+                                      d_kp_cur, d_desc_cur, d_uright_cur, d_cnt_cur, d_Tcw, d_level_mode, prm,
+                                      d_match_cur, d_nmatches, stream=None):
+    """Raw-pointer batch call of SearchByProjection on device-resident frame pairs (prm: ProjectionParams)."""
+    ex._check(lib().orbhip_search_by_projection_batch_device(ex._h, nframes, cap, d_kp_last, d_world_last, d_flags_last,
+                                                             d_desc_last, d_cnt_last, d_kp_cur, d_desc_cur, d_uright_cur,
+                                                             d_cnt_cur, d_Tcw, d_level_mode, C.byref(prm), d_match_cur,
+                                                             d_nmatches, stream))
+
+
 def ComputeStereoMatches(left, right, kp_l, desc_l, kp_r, desc_r, mb, mbf):
     """Frame::ComputeStereoMatches (reference src/Frame.cc:481-653) for the pair the two ORBextractor
     instances extracted last. Returns (mvuRight, mvDepth, matches kept)."""
