@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--kind", default="blocks", choices=["blocks", "noise", "lowc"])
     ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--stereo", action="store_true", help="step = left + right extraction + stereo matching of every pair; value = pairs/s")
+    ap.add_argument("--rectify", action="store_true", help="rectify every frame through cv::remap-style maps on the way into level 0")
     ap.add_argument("--color", type=int, default=0, choices=[0, 3, 4], help="feed interleaved BGR(A) frames: gray conversion fused into level 0")
     ap.add_argument("--host-fed", action="store_true", help="also time the PCIe-inclusive host-buffer entry point")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for the barrier / max-time reduction")
@@ -135,7 +136,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from visual_slam_amd import orbhip
+    from visual_slam_amd import orbhip, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -161,6 +162,8 @@ def main():
     w, h, nfeat, scale, levels, ini_th, min_th = WORKLOADS[args.workload]
     ex = orbhip.ORBextractor(nfeat, scale, levels, ini_th, min_th, device=local_rank, max_batch=args.max_batch)
     cap = ex.max_keypoints()
+    if args.rectify:
+        ex.set_rectification(*synth.rectify_maps(w, h))
     B = args.batch
     frames = make_batch_on_device(torch, args.kind, w, h, B, device)
     d_kp = torch.empty((B, cap, 7), dtype=torch.float32, device=device)
@@ -333,7 +336,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": args.workload, "image": [w, h], "nfeatures": nfeat, "levels": levels, "scale": scale,
                        "fast_th": [ini_th, min_th], "frames_per_gpu_per_step": B, "distribution": args.kind,
-                       "inputs": "device-resident" + (", %d-channel BGR" % args.color if args.color else ""), "pyramid_copied_back": False, "blur_variant": "legacy",
+                       "inputs": "device-resident" + (", %d-channel BGR" % args.color if args.color else "") + (", rectified by remap" if args.rectify else ""), "pyramid_copied_back": False, "blur_variant": "legacy",
                        "mean_keypoints_per_frame": round(n_out, 1), "sharding": "frames, no collective",
                        **({"stereo": True, "mean_matches_per_pair": round(float(d_nm.float().mean().item()), 1)} if args.stereo else {})},
             "roofline": roofline, "cpu_baseline": cpu,

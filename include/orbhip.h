@@ -138,6 +138,17 @@ int orbhip_debug_candidates(orbhip_extractor* e, int frame, int level, orbhip_ca
 int orbhip_enable_timing(orbhip_extractor* e, int on);
 int orbhip_get_timing(orbhip_extractor* e, const char** names, float* ms, int* launches, int cap);
 
+/* Rectification in front of the extraction: cv::remap(im, imRect, M1, M2, cv::INTER_LINEAR) as the
+ * stereo mains apply it to both images of every frame (Examples/Stereo/stereo_euroc.cc:136-137,
+ * Examples/ROS/ORB_SLAM2/src/ros_stereo.cc:161-162) with the CV_32F maps of
+ * cv::initUndistortRectifyMap (stereo_euroc.cc:97-98). map_x / map_y are host arrays of
+ * height x width floats (M1, M2: source column and row of every rectified pixel). Once set, every
+ * extraction call on this handle takes a gray image of that size, rectifies it on the way into
+ * pyramid level 0 (constant border 0 outside the source, as cv::remap's defaults) and works on the
+ * result; colour input and other sizes are refused. NULL, NULL clears the maps. Waits for the
+ * device; not to be called while a batch of this handle is in flight. */
+int orbhip_set_rectification(orbhip_extractor* e, const float* map_x, const float* map_y, int width, int height);
+
 /* Frame::ComputeStereoMatches (src/Frame.cc:481-653): for every left keypoint the right-image
  * column of its match (mvuRight) and its depth (mvDepth), -1 where there is none. `left` and
  * `right` are the two extractor instances of a stereo rig (mpORBextractorLeft / Right,

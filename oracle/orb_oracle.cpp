@@ -1254,4 +1254,84 @@ int orbo_search_by_projection(const orbo_keypoint* k_last, const float* world_la
     return nmatches;
 }
 
+/* cv::remap(src, dst, map1, map2, INTER_LINEAR, BORDER_CONSTANT, Scalar()) for an 8-bit single-channel
+ * image and CV_32FC1 maps (the rectification of reference Examples/Stereo/stereo_euroc.cc:136-137),
+ * OpenCV 2.4 .. 3.x imgproc/src/imgwarp.cpp: the maps become fixed point with INTER_BITS = 5
+ * (cvRound(map * 32): integer part saturated to short, 5-bit fraction index into the table), the
+ * table BilinearTab_i is built by initInterTab2D(INTER_LINEAR, true) exactly as below (15-bit weights,
+ * saturate_cast<short>, the sum forced to 32768 by the fix-up loop, which for the 2x2 kernel also
+ * looks at the following, still zero, table slots), remapBilinear applies it with
+ * FixedPtCast<int, uchar, 15> and treats taps outside the source as 0. dst has the maps' size. */
+void orbo_remap_linear(const uint8_t* src, int sw, int sh, size_t sstride, const float* map_x, const float* map_y,
+                       int dw, int dh, uint8_t* dst, size_t dstride) {
+    const int INTER_BITS = 5, INTER_TAB_SIZE = 1 << INTER_BITS, INTER_TAB_SIZE2 = INTER_TAB_SIZE * INTER_TAB_SIZE;
+    const int INTER_REMAP_COEF_BITS = 15, INTER_REMAP_COEF_SCALE = 1 << INTER_REMAP_COEF_BITS;
+    const int ksize = 2;
+    /* static, zero-initialised in OpenCV; a few slots of slack for the fix-up's look-ahead */
+    std::vector<short> tabi((size_t)INTER_TAB_SIZE2 * ksize * ksize + 16, 0);
+    std::vector<float> tab1((size_t)8 * INTER_TAB_SIZE);
+    const float scale = 1.f / INTER_TAB_SIZE;
+    for (int i = 0; i < INTER_TAB_SIZE; i++) {                 /* initInterTab1D, interpolateLinear */
+        const float x = i * scale;
+        tab1[i * ksize] = 1.f - x;
+        tab1[i * ksize + 1] = x;
+    }
+    auto sat_short = [](float v) {
+        int iv = (int)std::lrint(v);
+        return (short)std::min(std::max(iv, -32768), 32767);
+    };
+    short* itab = tabi.data();
+    for (int i = 0; i < INTER_TAB_SIZE; i++)
+        for (int j = 0; j < INTER_TAB_SIZE; j++, itab += ksize * ksize) {
+            int isum = 0;
+            for (int k1 = 0; k1 < ksize; k1++) {
+                const float vy = tab1[i * ksize + k1];
+                for (int k2 = 0; k2 < ksize; k2++) {
+                    const float v = vy * tab1[j * ksize + k2];
+                    isum += itab[k1 * ksize + k2] = sat_short(v * INTER_REMAP_COEF_SCALE);
+                }
+            }
+            if (isum != INTER_REMAP_COEF_SCALE) {
+                const int diff = isum - INTER_REMAP_COEF_SCALE;
+                const int ksize2 = ksize / 2;
+                int Mk1 = ksize2, Mk2 = ksize2, mk1 = ksize2, mk2 = ksize2;
+                for (int k1 = ksize2; k1 < ksize2 + 2; k1++)
+                    for (int k2 = ksize2; k2 < ksize2 + 2; k2++) {
+                        if (itab[k1 * ksize + k2] < itab[mk1 * ksize + mk2]) { mk1 = k1; mk2 = k2; }
+                        else if (itab[k1 * ksize + k2] > itab[Mk1 * ksize + Mk2]) { Mk1 = k1; Mk2 = k2; }
+                    }
+                if (diff < 0) itab[Mk1 * ksize + Mk2] = (short)(itab[Mk1 * ksize + Mk2] - diff);
+                else itab[mk1 * ksize + mk2] = (short)(itab[mk1 * ksize + mk2] - diff);
+            }
+        }
+    const short* wtab = tabi.data();
+    const unsigned width1 = (unsigned)std::max(sw - 1, 0), height1 = (unsigned)std::max(sh - 1, 0);
+    for (int dy = 0; dy < dh; dy++) {
+        uint8_t* D = dst + (size_t)dy * dstride;
+        for (int dx = 0; dx < dw; dx++) {
+            const int isx = (int)std::lrint(map_x[(size_t)dy * dw + dx] * INTER_TAB_SIZE);   /* cvRound */
+            const int isy = (int)std::lrint(map_y[(size_t)dy * dw + dx] * INTER_TAB_SIZE);
+            const int v = (isy & (INTER_TAB_SIZE - 1)) * INTER_TAB_SIZE + (isx & (INTER_TAB_SIZE - 1));
+            const int sx = std::min(std::max(isx >> INTER_BITS, -32768), 32767);
+            const int sy = std::min(std::max(isy >> INTER_BITS, -32768), 32767);
+            const short* w = wtab + v * 4;
+            int sum;
+            if ((unsigned)sx < width1 && (unsigned)sy < height1) {
+                const uint8_t* S = src + (size_t)sy * sstride + sx;
+                sum = S[0] * w[0] + S[1] * w[1] + S[sstride] * w[2] + S[sstride + 1] * w[3];
+            } else {
+                if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) { D[dx] = 0; continue; }   /* BORDER_CONSTANT, value 0 */
+                const int sx0 = sx, sx1 = sx + 1, sy0 = sy, sy1 = sy + 1;
+                const int v0 = (sx0 >= 0 && sx0 < sw && sy0 >= 0 && sy0 < sh) ? src[(size_t)sy0 * sstride + sx0] : 0;
+                const int v1 = (sx1 >= 0 && sx1 < sw && sy0 >= 0 && sy0 < sh) ? src[(size_t)sy0 * sstride + sx1] : 0;
+                const int v2 = (sx0 >= 0 && sx0 < sw && sy1 >= 0 && sy1 < sh) ? src[(size_t)sy1 * sstride + sx0] : 0;
+                const int v3 = (sx1 >= 0 && sx1 < sw && sy1 >= 0 && sy1 < sh) ? src[(size_t)sy1 * sstride + sx1] : 0;
+                sum = v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3];
+            }
+            const int r = (sum + (1 << (INTER_REMAP_COEF_BITS - 1))) >> INTER_REMAP_COEF_BITS;
+            D[dx] = (uint8_t)std::min(std::max(r, 0), 255);
+        }
+    }
+}
+
 } // extern "C"

@@ -119,6 +119,11 @@ int orbo_search_for_initialization(const orbo_keypoint* k1, const uint8_t* d1, i
                                    float* prev_matched, int windowSize, float mfNNratio, int mbCheckOrientation,
                                    int* matches12);
 
+/* cv::remap(src, dst, map1, map2, INTER_LINEAR) with constant border 0 for an 8-bit gray image and
+ * CV_32FC1 maps of size dw x dh (Examples/Stereo/stereo_euroc.cc:136-137). */
+void orbo_remap_linear(const uint8_t* src, int sw, int sh, size_t sstride, const float* map_x, const float* map_y,
+                       int dw, int dh, uint8_t* dst, size_t dstride);
+
 /* ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1324-1445) on
  * plain arrays; see orb_oracle.cpp for the meaning of every argument. Returns nmatches. */
 int orbo_search_by_projection(const orbo_keypoint* k_last, const float* world_last, const uint8_t* flags_last,

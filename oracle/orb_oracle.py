@@ -81,6 +81,8 @@ def lib():
                                                 C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                                 C.c_float, C.c_int, C.c_int, C.c_void_p]
         L.orbo_projection_level_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int]
+        L.orbo_remap_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_size_t]
         L.orbo_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
@@ -248,6 +250,16 @@ def search_by_projection(kp_last, world_last, flags_last, desc_last, kp_cur, des
                                         _ptr(np.ascontiguousarray(scale_factors, np.float32)), float(th), int(level_mode),
                                         int(bool(check_orientation)), _ptr(m))
     return m[:len(kp_cur)], n
+
+
+def remap_linear(img, map_x, map_y):
+    """cv::remap(img, dst, map_x, map_y, INTER_LINEAR) (constant border 0) of an (H, W) uint8 image; maps are float32."""
+    img = np.ascontiguousarray(img, np.uint8)
+    mx = np.ascontiguousarray(map_x, np.float32); my = np.ascontiguousarray(map_y, np.float32)
+    out = np.zeros(mx.shape, np.uint8)
+    lib().orbo_remap_linear(_ptr(img), img.shape[1], img.shape[0], img.strides[0], _ptr(mx), _ptr(my), mx.shape[1], mx.shape[0],
+                            _ptr(out), out.strides[0])
+    return out
 
 
 def cvt_gray(img, rgb):

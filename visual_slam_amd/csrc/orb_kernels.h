@@ -119,6 +119,93 @@ __global__ __launch_bounds__(256) void k_level0_color(const uint8_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Level 0 through a rectification: cv::remap(im, imRect, M1, M2, cv::INTER_LINEAR) of the stereo
+// mains (reference Examples/Stereo/stereo_euroc.cc:136-137, maps from cv::initUndistortRectifyMap(...,
+// CV_32F, M1, M2) at :97-98) fused into the level-0 kernel, border included (a border pixel is the
+// rectified value at the reflected coordinate). OpenCV's arithmetic for CV_32FC1 maps and 8-bit
+// images: position = cvRound(map * 32) (5 fractional bits), the four bilinear weights
+// (32 - fy | fy) * (32 - fx | fx) * 32 (their table of 15-bit weights; its (0,0) entry
+// {32767, 0, 0, 1} gives the same result as {32768, 0, 0, 0} on 8-bit data), result
+// (sum + 2^14) >> 15, taps outside the image count as 0 (BORDER_CONSTANT, value 0).
+// A thread owns 4 adjacent plane pixels; their source offsets and weights are computed once and
+// applied to RM_FR frames, so the maps are read once per RM_FR frames. A tap pair of a row is one
+// unaligned 16-bit load. A pair that straddles the image edge is moved inside and its weights are
+// moved or cleared accordingly.
+// ------------------------------------------------------------------------------------------------
+#define RM_FR 4
+
+typedef unsigned short v2us_t __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void k_level0_remap(const uint8_t* __restrict__ src, size_t row_stride, size_t frame_stride,
+                                                      int frames, const float* __restrict__ map_x,
+                                                      const float* __restrict__ map_y, uint8_t* __restrict__ pyr,
+                                                      LevelGeom g, int ndw) {
+    const int c4 = blockIdx.x * 64 + threadIdx.x;
+    const int r = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int f0 = blockIdx.z * RM_FR;
+    if (c4 >= ndw || r >= g.rows) return;
+    const int y = reflect101(r - ORB_OY, g.h);
+    uint32_t off[4], wa[4], wb[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int x = min(max(reflect101(4 * c4 + j - ORB_OX, g.w), 0), g.w - 1);   // columns of the row padding: anything inside
+        const float mx = map_x[(size_t)y * g.w + x], my = map_y[(size_t)y * g.w + x];
+        const int ix = __float2int_rn(mx * 32.0f), iy = __float2int_rn(my * 32.0f);     // cvRound
+        const int fx = ix & 31, fy = iy & 31;
+        const int sx = min(max(ix >> 5, -32768), 32767), sy = min(max(iy >> 5, -32768), 32767);   // saturate_cast<short>
+        // weights of the taps (sx, sy), (sx+1, sy), (sx, sy+1), (sx+1, sy+1); a tap outside the image is 0
+        uint32_t w00 = (uint32_t)((32 - fy) * (32 - fx) * 32), w01 = (uint32_t)((32 - fy) * fx * 32);
+        uint32_t w10 = (uint32_t)(fy * (32 - fx) * 32), w11 = (uint32_t)(fy * fx * 32);
+        const bool x0in = sx >= 0 && sx < g.w, x1in = sx + 1 >= 0 && sx + 1 < g.w;
+        const bool y0in = sy >= 0 && sy < g.h, y1in = sy + 1 >= 0 && sy + 1 < g.h;
+        if (!x0in) { w00 = 0; w10 = 0; }
+        if (!x1in) { w01 = 0; w11 = 0; }
+        if (!y0in) { w00 = 0; w01 = 0; }
+        if (!y1in) { w10 = 0; w11 = 0; }
+        // the loads read columns cx, cx+1 of rows cy, cy+1 with (cx, cy) inside [0, w-2] x [0, h-2]
+        const int cx = min(max(sx, 0), g.w - 2), cy = min(max(sy, 0), g.h - 2);
+        if (cx == sx + 1) { w00 = w01; w10 = w11; w01 = 0; w11 = 0; }        // sx = -1: its right tap is the left loaded byte
+        else if (cx == sx - 1) { w01 = w00; w11 = w10; w00 = 0; w10 = 0; }   // sx = w-1: its left tap is the right loaded byte
+        else if (cx != sx) { w00 = w01 = w10 = w11 = 0; }
+        if (cy == sy + 1) { w00 = w10; w01 = w11; w10 = 0; w11 = 0; }
+        else if (cy == sy - 1) { w10 = w00; w11 = w01; w00 = 0; w01 = 0; }
+        else if (cy != sy) { w00 = w01 = w10 = w11 = 0; }
+        off[j] = (uint32_t)cy * (uint32_t)row_stride + (uint32_t)cx;        // a frame is far below 4 GB
+        wa[j] = w00 | (w01 << 16);
+        wb[j] = w10 | (w11 << 16);
+    }
+    const int nf = min(RM_FR, frames - f0);
+    uint16_t lo[RM_FR][4], hi[RM_FR][4];
+#pragma unroll
+    for (int k = 0; k < RM_FR; k++) {
+        if (k < nf) {
+            const uint8_t* S = src + (size_t)(f0 + k) * frame_stride;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                __builtin_memcpy(&lo[k][j], S + off[j], 2);
+                __builtin_memcpy(&hi[k][j], S + off[j] + (uint32_t)row_stride, 2);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RM_FR; k++) {
+        if (k < nf) {
+            uint32_t out = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t a = __builtin_amdgcn_perm(0, lo[k][j], 0x0C010C00u);   // byte0 | byte1 << 16
+                const uint32_t b = __builtin_amdgcn_perm(0, hi[k][j], 0x0C010C00u);
+                const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(v2us_t, a), __builtin_bit_cast(v2us_t, wa[j]),
+                                   __builtin_amdgcn_udot2(__builtin_bit_cast(v2us_t, b), __builtin_bit_cast(v2us_t, wb[j]), 1u << 14, false), false) >> 15;
+                out |= v << (8 * j);
+            }
+            uint8_t* D = pyr + g.pyr_off + (size_t)(f0 + k) * g.plane_bytes;
+            *reinterpret_cast<uint32_t*>(D + (size_t)r * g.pitch + 4 * c4) = out;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Level l from level l-1: cv::resize(8UC1, INTER_LINEAR) fixed-point arithmetic, border included
 // (a border pixel is the resized value at the reflected coordinate, which is what copyMakeBorder
 // copies there). The tap tables are built on the host exactly as OpenCV builds xofs/ialpha and

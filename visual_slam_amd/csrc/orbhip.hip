@@ -74,6 +74,9 @@ struct orbhip_extractor {
     hipEvent_t ev_order = nullptr;   // orders work of another instance (stereo matching) against this one's stream
     hipStream_t last_stream = nullptr;   // stream of the last batch call
     int* d_status = nullptr;       // bit0 candidate overflow, bit1 output capacity
+    float* d_map_x = nullptr;      // rectification maps (orbhip_set_rectification), map_w x map_h floats each
+    float* d_map_y = nullptr;
+    int map_w = 0, map_h = 0;
     size_t qt_lds = 0;
     int last_pass_frames = 0;
     int last_ws = 0;               // workspace of the last pass (pyramid / candidate read-back)
@@ -314,7 +317,11 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
         // 16-byte groups [i_lo, i_hi) lie inside the image: straight dwordx4 copies when the
         // source is aligned; the groups that touch the border go through the reflecting byte path
         const int i_lo = ORB_OX / 16, i_hi = (ORB_OX + g.w) / 16;
-        if (channels != 1) {
+        if (e->d_map_x) {                                      // gray input through the rectification maps
+            const int ndw = n16 * 4;
+            hipLaunchKernelGGL(k_level0_remap, dim3((ndw + 63) / 64, (g.rows + 3) / 4, (frames + RM_FR - 1) / RM_FR), blk2, 0, s,
+                               d_imgs, row_stride, frame_stride, frames, e->d_map_x, e->d_map_y, W.d_pyr, g, ndw);
+        } else if (channels != 1) {
             const dim3 grid((g.rows * n16 + 255) / 256, frames);
             if (channels == 3)
                 hipLaunchKernelGGL(k_level0_color<3>, grid, dim3(256), 0, s, d_imgs, row_stride, frame_stride, W.d_pyr, g, n16, rgb, aligned16);
@@ -462,6 +469,7 @@ int orbhip_destroy(orbhip_extractor* e) {
     free_plan(e);
     dfree(e->d_status); dfree(e->d_in); dfree(e->d_out_kp); dfree(e->d_out_desc); dfree(e->d_out_cnt);
     dfree(e->d_st_sad); dfree(e->d_st_rinfo); dfree(e->d_st_bins); dfree(e->d_st_tmp);
+    dfree(e->d_map_x); dfree(e->d_map_y);
     if (e->h_in) (void)hipHostFree(e->h_in);
     if (e->h_out) (void)hipHostFree(e->h_out);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -482,6 +490,10 @@ static int extract_device_impl(orbhip_extractor* e, const uint8_t* d_imgs, int n
         return ORBHIP_ERR_ARG;
     if (!d_imgs || width <= 0 || height <= 0 || nframes == 0) return ORBHIP_ERR_EMPTY;
     if (row_stride < (size_t)width * channels) return ORBHIP_ERR_ARG;
+    if (e->d_map_x && (channels != 1 || width != e->map_w || height != e->map_h || width < 2 || height < 2)) {
+        e->err = "rectification maps are set: the input must be a gray image of the maps' size";
+        return ORBHIP_ERR_ARG;
+    }
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     e->last_stream = s;
@@ -1003,6 +1015,23 @@ int orbhip_search_for_initialization(orbhip_extractor* e, const orbhip_keypoint*
     HIP_TRY(e, hipMemcpy(prev_matched, d_prev, (size_t)n1 * 2 * sizeof(float), hipMemcpyDeviceToHost));
     HIP_TRY(e, hipMemcpy(matches12, d_m12, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost));
     HIP_TRY(e, hipMemcpy(nmatches, d_cnt + 2, sizeof(int), hipMemcpyDeviceToHost));
+    return ORBHIP_OK;
+}
+
+int orbhip_set_rectification(orbhip_extractor* e, const float* map_x, const float* map_y, int width, int height) {
+    if (!e) return ORBHIP_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipDeviceSynchronize());                        // no pass may still read the old maps
+    dfree(e->d_map_x); dfree(e->d_map_y);
+    e->map_w = e->map_h = 0;
+    if (!map_x && !map_y) return ORBHIP_OK;
+    if (!map_x || !map_y || width < 2 || height < 2) return ORBHIP_ERR_ARG;
+    const size_t bytes = (size_t)width * height * sizeof(float);
+    HIP_TRY(e, hipMalloc(&e->d_map_x, bytes));
+    HIP_TRY(e, hipMalloc(&e->d_map_y, bytes));
+    HIP_TRY(e, hipMemcpy(e->d_map_x, map_x, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->d_map_y, map_y, bytes, hipMemcpyHostToDevice));
+    e->map_w = width; e->map_h = height;
     return ORBHIP_OK;
 }
 

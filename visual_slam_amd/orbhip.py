@@ -35,6 +35,7 @@ EXPORTS = [
     "orbhip_image_bounds", "orbhip_undistort_grid", "orbhip_undistort_grid_batch_device",
     "orbhip_search_for_initialization", "orbhip_search_for_initialization_batch_device",
     "orbhip_search_by_projection", "orbhip_search_by_projection_batch_device", "orbhip_projection_level_mode",
+    "orbhip_set_rectification",
 ]
 
 
@@ -100,6 +101,7 @@ def lib():
         L.orbhip_search_by_projection_batch_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                                                vp, vp, vp]
         L.orbhip_projection_level_mode.argtypes = [vp, vp, C.c_float, C.c_int]
+        L.orbhip_set_rectification.argtypes = [vp, vp, vp, C.c_int, C.c_int]
         L.orbhip_stereo_match.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, ip]
         L.orbhip_stereo_match_batch_device.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float,
                                                        vp, vp, vp, vp]
@@ -312,6 +314,17 @@ class ORBextractor:
         """Raw-pointer batch call on device-resident interleaved colour frames (strides in bytes)."""
         self._check(lib().orbhip_extract_batch_device_color(self._h, d_imgs, nframes, w, h, row_stride, frame_stride,
                                                             channels, int(bool(rgb)), d_kp, d_desc, d_counts, cap, stream))
+
+    def set_rectification(self, map_x=None, map_y=None):
+        """cv::remap(im, imRect, M1, M2, INTER_LINEAR) in front of every extraction (reference
+        Examples/Stereo/stereo_euroc.cc:97-98,136-137): map_x / map_y are (H, W) float32 arrays; None clears."""
+        if map_x is None and map_y is None:
+            self._check(lib().orbhip_set_rectification(self._h, None, None, 0, 0))
+            return
+        mx = np.ascontiguousarray(map_x, np.float32); my = np.ascontiguousarray(map_y, np.float32)
+        if mx.ndim != 2 or mx.shape != my.shape:
+            raise ValueError("map_x and map_y must be 2-D arrays of the same shape")
+        self._check(lib().orbhip_set_rectification(self._h, _ptr(mx), _ptr(my), mx.shape[1], mx.shape[0]))
 
     def synchronize(self):
         self._check(lib().orbhip_synchronize(self._h))

@@ -51,3 +51,15 @@ def stereo_pair(kind, w, h, index=0, disparities=(3, 12, 40)):
         right[r0:r1, :w - d] = left[r0:r1, d:]
         right[r0:r1, w - d:] = left[r0:r1, w - d:]
     return left, right
+
+
+def rectify_maps(w, h, angle_deg=1.7, k=0.09, shift=(3.3, -2.6)):
+    """Float32 maps (map_x, map_y) of the kind cv::initUndistortRectifyMap produces for a stereo rig:
+    a small rotation, a radial term and a shift; parts of the rectified image look outside the source."""
+    x, y = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    cx, cy, f = w / 2.0 - 0.5, h / 2.0 - 0.5, 0.9 * w
+    a = np.deg2rad(angle_deg)
+    xn, yn = (x - cx) / f, (y - cy) / f
+    xr, yr = np.cos(a) * xn - np.sin(a) * yn, np.sin(a) * xn + np.cos(a) * yn
+    d = 1.0 + k * (xr * xr + yr * yr)
+    return (xr * d * f + cx + shift[0]).astype(np.float32), (yr * d * f + cy + shift[1]).astype(np.float32)
