@@ -98,6 +98,21 @@ void ORBextractor::operator()( cv::InputArray _image, cv::InputArray _mask, std:
     }
 }
 
+void ORBextractor::SetRectification(const cv::Mat& M1, const cv::Mat& M2)
+{
+    if (M1.empty() && M2.empty())
+    {
+        check(orbhip_set_rectification(mpHandle, NULL, NULL, 0, 0), mpHandle, "set_rectification");
+        return;
+    }
+    // dense rows of floats
+    std::vector<float> mx((size_t)M1.rows * M1.cols), my((size_t)M2.rows * M2.cols);
+    for (int y = 0; y < M1.rows; y++) std::memcpy(&mx[(size_t)y * M1.cols], M1.ptr(y), (size_t)M1.cols * sizeof(float));
+    for (int y = 0; y < M2.rows; y++) std::memcpy(&my[(size_t)y * M2.cols], M2.ptr(y), (size_t)M2.cols * sizeof(float));
+    check(M1.rows == M2.rows && M1.cols == M2.cols ? 0 : ORBHIP_ERR_ARG, mpHandle, "set_rectification (map sizes)");
+    check(orbhip_set_rectification(mpHandle, mx.data(), my.data(), M1.cols, M1.rows), mpHandle, "set_rectification");
+}
+
 // Frame::ComputeStereoMatches (reference src/Frame.cc:481-653)
 void ORBextractor::ComputeStereoMatches(ORBextractor& left, ORBextractor& right,
                                         const std::vector<cv::KeyPoint>& keysLeft, const cv::Mat& descLeft,

@@ -69,6 +69,15 @@ public:
 
     void SetPyramidFetch(bool on) { mbFetchPyramid = on; }
 
+    // Rectification in front of the extraction (extension): the cv::remap(im, imRect, M1, M2,
+    // cv::INTER_LINEAR) of the stereo mains (reference Examples/Stereo/stereo_euroc.cc:97-98, 136-137)
+    // runs on the GPU on the way into pyramid level 0. M1 / M2 are the CV_32F maps of
+    // cv::initUndistortRectifyMap; empty Mats switch it off again.
+    void SetRectification(const cv::Mat& M1, const cv::Mat& M2);
+
+    // The C handle, for the other entry points of orbhip.h (undistortion + grid, matchers).
+    orbhip_extractor* Handle() { return mpHandle; }
+
     // Frame::ComputeStereoMatches (reference src/Frame.cc:481-653) on the GPU, for the pair of images
     // the two instances extracted last: fills mvuRight / mvDepth (-1 = no match). With it the body
     // of Frame::ComputeStereoMatches is one call and the pyramids need not be fetched

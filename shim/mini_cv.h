@@ -11,6 +11,8 @@
 
 #define CV_8U 0
 #define CV_8UC1 0
+#define CV_32F 5
+#define CV_32FC1 5
 
 typedef unsigned char uchar;
 
@@ -48,30 +50,32 @@ public:
     size_t step = 0;
     uchar* data = nullptr;
     Mat() {}
-    Mat(int r, int c, int) { create(r, c, CV_8U); }
-    Mat(Size s, int) { create(s.height, s.width, CV_8U); }
-    void create(int r, int c, int) {
-        if (r == rows && c == cols && buf_ && step == (size_t)c) return;
-        rows = r; cols = c; step = (size_t)c;
-        buf_ = std::shared_ptr<uchar>(new uchar[(size_t)r * c + 1], std::default_delete<uchar[]>());
+    Mat(int r, int c, int t) { create(r, c, t); }
+    Mat(Size s, int t) { create(s.height, s.width, t); }
+    void create(int r, int c, int t) {
+        const size_t esz = t == CV_32F ? 4 : 1;
+        if (r == rows && c == cols && buf_ && step == (size_t)c * esz && t == type_) return;
+        rows = r; cols = c; step = (size_t)c * esz; type_ = t;
+        buf_ = std::shared_ptr<uchar>(new uchar[(size_t)r * step + 1], std::default_delete<uchar[]>());
         data = buf_.get();
     }
     void release() { rows = cols = 0; step = 0; data = nullptr; buf_.reset(); }
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
-    int type() const { return CV_8UC1; }
+    int type() const { return type_; }
     uchar* ptr(int r = 0) { return data + (size_t)r * step; }
     const uchar* ptr(int r = 0) const { return data + (size_t)r * step; }
     template <typename T> T& at(int r, int c) { return *reinterpret_cast<T*>(data + (size_t)r * step + c * sizeof(T)); }
     template <typename T> const T& at(int r, int c) const { return *reinterpret_cast<const T*>(data + (size_t)r * step + c * sizeof(T)); }
     Mat operator()(const Rect& r) const {
         Mat m;
-        m.rows = r.height; m.cols = r.width; m.step = step;
-        m.data = data + (size_t)r.y * step + r.x;
+        m.rows = r.height; m.cols = r.width; m.step = step; m.type_ = type_;
+        m.data = data + (size_t)r.y * step + (size_t)r.x * (type_ == CV_32F ? 4 : 1);
         m.buf_ = buf_;
         return m;
     }
 private:
     std::shared_ptr<uchar> buf_;
+    int type_ = CV_8UC1;
 };
 
 class _InputArray {

@@ -95,6 +95,35 @@ int main()
         orbo_destroy(oR);
         std::printf("shim stereo ok: %d of %d left keypoints matched\n", matched, on);
     }
+    // rectification through the class: level 0 is cv::remap of the input as the oracle restates it
+    {
+        cv::Mat M1(H, W, CV_32FC1), M2(H, W, CV_32FC1);
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                reinterpret_cast<float*>(M1.ptr(y))[x] = x + 2.3f + 0.01f * y;
+                reinterpret_cast<float*>(M2.ptr(y))[x] = y - 1.6f + 0.02f * x;
+            }
+        std::vector<float> mx((size_t)W * H), my((size_t)W * H);
+        for (int y = 0; y < H; y++) {
+            std::memcpy(&mx[(size_t)y * W], M1.ptr(y), (size_t)W * 4);
+            std::memcpy(&my[(size_t)y * W], M2.ptr(y), (size_t)W * 4);
+        }
+        std::vector<unsigned char> rect((size_t)W * H);
+        orbo_remap_linear(img.data, W, H, img.step, mx.data(), my.data(), W, H, rect.data(), (size_t)W);
+        ORB_SLAM2::ORBextractor exq(1200, 1.2f, 8, 20, 7);
+        exq.SetRectification(M1, M2);
+        std::vector<cv::KeyPoint> kq;
+        cv::Mat dq;
+        exq(img, cv::Mat(), kq, dq);
+        int bad = 0;
+        for (int y = 0; y < H; y++) bad += std::memcmp(exq.mvImagePyramid[0].ptr(y), &rect[(size_t)y * W], (size_t)W) != 0;
+        CHECK(bad == 0 && kq.size() > 300);
+        exq.SetRectification(cv::Mat(), cv::Mat());
+        std::vector<cv::KeyPoint> kq2;
+        exq(img, cv::Mat(), kq2, dq);
+        CHECK(kq2.size() == kps.size());
+        std::printf("shim rectification ok: %d keypoints on the rectified image\n", (int)kq.size());
+    }
     // empty input leaves the outputs untouched; second call replaces them
     std::vector<cv::KeyPoint> keep = kps;
     ex(cv::Mat(), cv::Mat(), kps, desc);
