@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Random-parameter sweep of the device paths next to the extraction (rectification, the two
+matchers) against the oracle. One-off robustness tool: prints the failing draws, exit status 1 if any.
+
+Usage: python tools/fuzz_next_rows.py [--cases 60] [--seed 1]
+"""
+import argparse
+import pathlib
+import sys
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from oracle import orb_oracle as O  # noqa: E402
+from visual_slam_amd import orbhip, synth  # noqa: E402
+
+
+def shifted(img, dx, dy):
+    out = img.copy()
+    h, w = img.shape
+    out[max(dy, 0):h + min(dy, 0), max(dx, 0):w + min(dx, 0)] = img[max(-dy, 0):h + min(-dy, 0), max(-dx, 0):w + min(-dx, 0)]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    bad = 0
+    for case in range(args.cases):
+        w = int(rng.integers(160, 900)); h = int(rng.integers(120, 600))
+        nfeat = int(rng.choice([300, 800, 1500]))
+        kind = str(rng.choice(["blocks", "lowc", "noise"]))
+        prm = (nfeat, 1.2, int(rng.integers(3, 9)), 20, 7)
+        img = synth.frame(kind, w, h, 1000 + case)
+        tag = "case %d %dx%d %s n%d l%d" % (case, w, h, kind, nfeat, prm[2])
+        try:
+            o = O.OracleExtractor(*prm)
+            ex = orbhip.ORBextractor(*prm)
+        except (RuntimeError, orbhip.OrbHipError) as e:
+            print(tag, "skipped:", e); continue
+        # rectification with random strength, partly far outside the source
+        mx, my = synth.rectify_maps(w, h, float(rng.uniform(-8, 8)), float(rng.uniform(-0.5, 0.5)),
+                                    (float(rng.uniform(-40, 40)), float(rng.uniform(-40, 40))))
+        if rng.random() < 0.3:
+            mx = mx + rng.uniform(-0.01, 0.01, mx.shape).astype(np.float32)     # rounding ties of the 1/32 grid
+        rect = O.remap_linear(img, mx, my)
+        ex.set_rectification(mx, my)
+        try:
+            kp, desc = ex(img)
+            okp, odesc = o.extract(rect)
+            ok = np.array_equal(ex.pyramid_level(0, with_border=True), o.level(0, with_border=True)) and len(kp) == len(okp) and \
+                np.array_equal(desc, odesc)
+        except (RuntimeError, orbhip.OrbHipError) as e:
+            print(tag, "extract refused:", e); ex.set_rectification(None, None); continue
+        if not ok:
+            bad += 1; print(tag, "RECTIFICATION MISMATCH")
+        ex.set_rectification(None, None)
+        # matchers on (img, shifted img)
+        dx, dy = int(rng.integers(-20, 21)), int(rng.integers(-12, 13))
+        cam = (float(rng.uniform(300, 900)), float(rng.uniform(300, 900)), w / 2.0 + float(rng.uniform(-20, 20)), h / 2.0, 0.0, 0, 0, 0, 0)
+        if rng.random() < 0.5:
+            cam = cam[:4] + (float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.2, 0.2)), 0.001, -0.002, 0.0)
+        k1, d1 = o.extract(img)
+        k2, d2 = o.extract(shifted(img, dx, dy))
+        if len(k1) == 0 or len(k2) == 0:
+            continue
+        bounds = O.image_bounds(cam, w, h)
+        u1 = O.undistort_grid(cam, bounds, k1)[0]; u2 = O.undistort_grid(cam, bounds, k2)[0]
+        Z = float(rng.uniform(2, 20))
+        fx, fy, cx, cy = cam[:4]
+        world = np.stack([(u1["x"] - cx) * Z / fx, (u1["y"] - cy) * Z / fy, np.full(len(u1), Z)], axis=1).astype(np.float32)
+        world += rng.normal(0, 0.01, world.shape).astype(np.float32)
+        a = float(rng.uniform(-0.02, 0.02))
+        R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+        Tcw = np.concatenate([R.ravel(), [dx * Z / fx, dy * Z / fy, float(rng.uniform(-0.3, 0.3))]]).astype(np.float32)
+        flags = ((rng.random(len(u1)) < 0.8).astype(np.uint8) | ((rng.random(len(u1)) < rng.random()).astype(np.uint8) << 1))
+        ur = None
+        if rng.random() < 0.5:
+            ur = (u2["x"] - 0.4 * fx / Z + rng.normal(0, 3, len(u2))).astype(np.float32)
+            ur[rng.random(len(u2)) < 0.3] = -1
+        th = float(rng.choice([3, 7, 15, 30])); mode = int(rng.integers(0, 3)); ori = bool(rng.random() < 0.7)
+        sf = o.table(0)
+        om, on = O.search_by_projection(u1, world, flags, d1, u2, d2, ur, Tcw, cam[:4], 0.4 * fx, bounds, sf, th, mode, ori)
+        gm, gn = orbhip.SearchByProjection(ex, u1, world, flags, d1, u2, d2, ur, Tcw, cam[:4], 0.4 * fx, bounds, th, mode, ori)
+        if gn != on or not np.array_equal(gm, om):
+            bad += 1; print(tag, "PROJECTION MISMATCH", gn, on, int((gm != om).sum()))
+        prev = np.stack([u1["x"], u1["y"]], axis=1)
+        win = int(rng.choice([20, 100])); ratio = float(rng.choice([0.7, 0.9]))
+        om12, op, on2 = O.search_for_initialization(u1, d1, u2, d2, bounds, prev, win, ratio, ori)
+        gm12, gp, gn2 = orbhip.SearchForInitialization(ex, u1, d1, u2, d2, bounds, prev, win, ratio, ori)
+        if gn2 != on2 or not np.array_equal(gm12, om12) or not np.array_equal(gp.view(np.uint32), op.view(np.uint32)):
+            bad += 1; print(tag, "INITIALIZATION MISMATCH", gn2, on2)
+    print("fuzz: %d cases, %d mismatches" % (args.cases, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
