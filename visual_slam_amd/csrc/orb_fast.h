@@ -25,14 +25,14 @@
 //   score  (sparse) : queued pixels are taken 128 at a time, two per lane in the halves of packed
 //                     16-bit values (a remainder waits for the next step and the last one is
 //                     taken one per lane if it is small): 16 ring bytes from the LDS image tile, exact score,
-//                     written to a byte map of the tile in LDS, plus one bit per scored pixel
-//                     in an occupancy map.
-//   nms    (sparse) : after a barrier every wave reads the occupancy bits of its 8 map rows,
-//                     compacts the scored pixels the same way and handles them one per lane:
+//                     written to a byte map of the tile in LDS; the position of a scored output
+//                     pixel is also appended to a list of the tile (ballot + one LDS add per batch).
+//   nms    (sparse) : after a barrier the waves share the list, one entry per lane:
 //                     non-maximum suppression inside the cell (all eight neighbour reads in
 //                     flight), then a plain store into the wave's own output segment
 //                     (no atomics, no ordering between waves: the consumer does not depend on
-//                     the order of the candidates).
+//                     the order of the candidates). A tile with more scored pixels than the
+//                     list holds (dense texture) finds them by scanning the map instead.
 // Row bookkeeping is wave-uniform and runs on the scalar unit; tiles are taken in an XCD-aware
 // order so that the rows and cache lines neighbouring tiles share are fetched from memory once.
 #pragma once
@@ -121,7 +121,8 @@ __device__ __forceinline__ v2s fast_score16_pk(v2s v, const v2s (&p)[16]) {
 #define FT_MAP_ROWS 34     // tile rows -1 .. 32
 #define FT_IMG_ROWS 40     // tile rows -4 .. 35
 #define FT_QUEUE 256       // compaction window per wave
-#define FT_SEGCAP 768      // output segment of one wave: 8 rows x 248 columns after NMS hold < 700 survivors
+#define FT_SEGCAP 768      // output segment of one wave: a quarter of a tile's survivors (< 2000) plus a batch, or 8 rows x 248 columns
+#define FT_LIST 832        // scored output pixels a tile can list (sized so that 7 workgroups fit a CU's LDS)
 
 // Inclusive prefix sum over the 64 lanes with DPP row shifts and row broadcasts.
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
@@ -149,12 +150,42 @@ __device__ __forceinline__ void fast_fill_queue(uint32_t bits, int idx, int lo, 
     }
 }
 
+// Appends the tile positions (map row << 8 | tile column) of this batch's scored output pixels to the
+// tile's list: `hit` lanes are numbered with a ballot, one lane reserves the range with an LDS add.
+// Entries beyond the list's capacity are dropped; the counter keeps counting, which tells the
+// consumer to scan the map instead.
+__device__ __forceinline__ void fast_list_append(bool hit_a, uint32_t code_a, bool hit_b, uint32_t code_b, int lane,
+                                                 uint16_t* list, int* nlist) {
+    const unsigned long long ma = __ballot(hit_a), mb = __ballot(hit_b);
+    if (ma | mb) {                                             // wave-uniform
+        const int na = __popcll(ma);
+        int base = 0;
+        if (lane == 0) base = atomicAdd(nlist, na + __popcll(mb));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (hit_a) {
+            const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0));
+            if (slot < FT_LIST) list[slot] = (uint16_t)code_a;
+        }
+        if (hit_b) {
+            const int slot = base + na + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0));
+            if (slot < FT_LIST) list[slot] = (uint16_t)code_b;
+        }
+    }
+}
+
+// true for a map position that is an output pixel of the tile (map rows 1..32, tile columns 4..251);
+// the rest of the map is the one-pixel halo that only serves as neighbours
+__device__ __forceinline__ bool fast_is_output(int row, int xl) {
+    return (unsigned)(row - 1) < (unsigned)FT_ROWS && (unsigned)(xl - 4) < (unsigned)FT_COLS;
+}
+
 // Scores `n` (<= 64) queued pixels, one per lane, from the LDS image tile into the tile map.
 // Queue entry: step << 11 | lane << 5 | b with b = 8 * pixel + 7 - row (the sieve's verdict word);
 // map row = m0 + FT_GROUP * step + row, image tile row = map row + 3.
-// A pixel that reaches min_th also sets its bit in `occ` (8 words per map row, bit = tile column).
 __device__ __forceinline__ void fast_score_queue(const uint16_t* queue, int n, int lane, int m0, const uint8_t* img,
-                                                 int min_th, uint8_t* map, uint32_t* occ) {
+                                                 int min_th, uint8_t* map, uint16_t* list, int* nlist) {
+    bool hit = false;
+    uint32_t code = 0;
     if (lane < n) {
         const uint32_t e = queue[lane];
         const int xl = (int)((e >> 3) & 0xFC) + (int)((e >> 3) & 3);        // 4 * lane + pixel
@@ -168,15 +199,17 @@ __device__ __forceinline__ void fast_score_queue(const uint16_t* queue, int n, i
         const int s = fast_score16(c[0], p);
         if (s >= min_th) {
             map[row * FT_P + xl] = (uint8_t)s;
-            atomicOr(&occ[row * 8 + (xl >> 5)], 1u << (xl & 31));
+            hit = fast_is_output(row, xl);
+            code = (uint32_t)(row << 8 | xl);
         }
     }
+    fast_list_append(hit, code, false, 0, lane, list, nlist);
 }
 
 // Scores `n` (64 < n <= 128) queued pixels, two per lane (entries lane and lane + 64), with packed
 // 16-bit arithmetic. A lane without a second entry scores its first one twice.
 __device__ __forceinline__ void fast_score_queue2(const uint16_t* queue, int n, int lane, int m0, const uint8_t* img,
-                                                  int min_th, uint8_t* map, uint32_t* occ) {
+                                                  int min_th, uint8_t* map, uint16_t* list, int* nlist) {
     const bool two = lane + 64 < n;
     const uint32_t ea = queue[lane], eb = queue[two ? lane + 64 : lane];
     const int xa = (int)((ea >> 3) & 0xFC) + (int)((ea >> 3) & 3), xb = (int)((eb >> 3) & 0xFC) + (int)((eb >> 3) & 3);
@@ -190,14 +223,11 @@ __device__ __forceinline__ void fast_score_queue2(const uint16_t* queue, int n, 
     for (int k = 0; k < 16; k++) p[k] = v2s{(short)ca[ring[k]], (short)cb[ring[k]]};
     const v2s v = {(short)ca[0], (short)cb[0]};
     const v2s s = fast_score16_pk(v, p);
-    if (s.x >= min_th) {
-        map[ra * FT_P + xa] = (uint8_t)s.x;
-        atomicOr(&occ[ra * 8 + (xa >> 5)], 1u << (xa & 31));
-    }
-    if (two && s.y >= min_th) {
-        map[rb * FT_P + xb] = (uint8_t)s.y;
-        atomicOr(&occ[rb * 8 + (xb >> 5)], 1u << (xb & 31));
-    }
+    const bool sa = s.x >= min_th, sb = two && s.y >= min_th;
+    if (sa) map[ra * FT_P + xa] = (uint8_t)s.x;
+    if (sb) map[rb * FT_P + xb] = (uint8_t)s.y;
+    fast_list_append(sa && fast_is_output(ra, xa), (uint32_t)(ra << 8 | xa), sb && fast_is_output(rb, xb), (uint32_t)(rb << 8 | xb),
+                     lane, list, nlist);
 }
 
 // Grid: (tiles in x, tiles in y, frames). Output: segment (tile, wave) of FT_SEGCAP entries
@@ -209,7 +239,8 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
     __shared__ __align__(16) uint8_t s_map[FT_MAP_ROWS * FT_P];
     __shared__ __align__(16) uint8_t s_img[FT_IMG_ROWS * FT_P];
     __shared__ uint16_t s_queue[4][FT_QUEUE];
-    __shared__ uint32_t s_occ[FT_MAP_ROWS * 8];                // bit per map pixel: it holds a score
+    __shared__ uint16_t s_list[FT_LIST];                       // scored output pixels of the tile
+    __shared__ int s_nlist;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: row bookkeeping runs on the scalar unit
@@ -225,7 +256,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
     // map row m <-> level row y0 - 1 + m; image tile row t <-> level row y0 - 4 + t
 
     for (int i = tid; i < FT_MAP_ROWS * FT_P / 8; i += 256) reinterpret_cast<uint2*>(s_map)[i] = make_uint2(0, 0);
-    for (int i = tid; i < FT_MAP_ROWS * 8; i += 256) s_occ[i] = 0;
+    if (tid == 0) s_nlist = 0;
 
     // ---- sieve: map rows m0 .. m0+nrows-1 of this wave (9, 9, 8, 8 rows), five rows per step
     const int m0 = wv < 2 ? 9 * wv : 2 + 8 * wv;
@@ -325,7 +356,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
             const uint32_t code0 = ((uint32_t)grp << 11) | ((uint32_t)lane << 5);
             auto drain = [&](int n) {                          // n entries queued: score the full double batches
                 const int nfull = n & ~127;
-                for (int q = 0; q < nfull; q += 128) fast_score_queue2(queue + q, 128, lane, m0, s_img, min_th, s_map, s_occ);
+                for (int q = 0; q < nfull; q += 128) fast_score_queue2(queue + q, 128, lane, m0, s_img, min_th, s_map, s_list, &s_nlist);
                 pending = n - nfull;
                 if (nfull) {                                   // move the remainder (< 128 entries) to the front
                     const uint16_t v0 = queue[nfull + lane], v1 = queue[min(nfull + 64 + lane, FT_QUEUE - 1)];
@@ -346,61 +377,79 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
             }
         }
     }
-    if (pending > 64) fast_score_queue2(queue, pending, lane, m0, s_img, min_th, s_map, s_occ);
-    else if (pending) fast_score_queue(queue, pending, lane, m0, s_img, min_th, s_map, s_occ);
+    if (pending > 64) fast_score_queue2(queue, pending, lane, m0, s_img, min_th, s_map, s_list, &s_nlist);
+    else if (pending) fast_score_queue(queue, pending, lane, m0, s_img, min_th, s_map, s_list, &s_nlist);
     __syncthreads();                                           // all scores of the tile are in the map
 
-    // ---- non-maximum suppression inside the cell and emission, map rows 1+8*wv .. 8+8*wv
+    // ---- non-maximum suppression inside the cell and emission
     const int segi = (by * (int)gridDim.x + bx) * 4 + wv;
     uint2* out = seg + (size_t)f * seg_per_frame + g.seg_off + (size_t)segi * FT_SEGCAP;
     int nout = 0;
-    const int mh = 1 + 8 * wv;
-    uint32_t bits = 0;
-    if (lane >= 1 && lane <= 62) {                             // lanes 0 and 63 hold neighbour columns only
-        // rows outside the detectable area were never scored: their bits are zero
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t v = s_occ[(mh + j) * 8 + (lane >> 3)];
-            bits |= ((v >> (4 * (lane & 7))) & 0xFu) << (4 * j);
+    // One scored output pixel per lane: tile column xl, map row m. Neighbours in another cell (or
+    // outside the detectable area, where the map is 0) do not count.
+    auto nms_emit = [&](bool have, int xl, int m) __attribute__((always_inline)) {
+        bool keep = false;
+        int x = 0, y = 0, s = 0;
+        if (have) {
+            const uint8_t* c = &s_map[m * FT_P + xl];
+            s = c[0];
+            x = xs - 4 + xl; y = y0 - 1 + m;
+            const int ux = x - ORB_EDGE, uy = y - ORB_EDGE;
+            const int xin = ux - __mul24((int)__umulhi((uint32_t)ux, g.wcell_magic), g.wcell);
+            const int yin = uy - __mul24((int)__umulhi((uint32_t)uy, g.hcell_magic), g.hcell);
+            const bool l = xin > 0, r = xin < g.wcell - 1, u = yin > 0, d = yin < g.hcell - 1;
+            // all eight reads are in range (the map has a one-pixel halo); issue them together
+            const int nw_ = c[-FT_P - 1], n_ = c[-FT_P], ne_ = c[-FT_P + 1], w_ = c[-1], e_ = c[1];
+            const int sw_ = c[FT_P - 1], s_ = c[FT_P], se_ = c[FT_P + 1];
+            const int mu = max(max(l ? nw_ : 0, n_), r ? ne_ : 0);
+            const int md = max(max(l ? sw_ : 0, s_), r ? se_ : 0);
+            const int mc = max(l ? w_ : 0, r ? e_ : 0);
+            keep = s > max(max(u ? mu : 0, d ? md : 0), mc);
         }
-    }
-    if (__ballot(bits != 0)) {
-        const uint32_t cnt = __popc(bits);
-        const uint32_t incl = wave_scan_incl(cnt);
-        const int total = (int)__shfl(incl, 63, 64);
-        const int first = (int)(incl - cnt);
-        for (int wb = 0; wb < total; wb += FT_QUEUE) {
-            if (total <= FT_QUEUE) fast_fill_queue<false>(bits, first, 0, (uint32_t)lane << 5, queue);
-            else fast_fill_queue<true>(bits, first - wb, 0, (uint32_t)lane << 5, queue);
-            const int nw = min(FT_QUEUE, total - wb);
-            for (int q = 0; q < nw; q += 64) {
-                bool keep = false;
-                int x = 0, y = 0, s = 0;
-                if (q + lane < nw) {
-                    const uint32_t e = queue[q + lane];                   // lane << 5 | 4 * row + pixel
-                    const int xl = (int)((e >> 3) & 0xFC) + (int)(e & 3), m = mh + (int)((e >> 2) & 7);
-                    const uint8_t* c = &s_map[m * FT_P + xl];
-                    s = c[0];
-                    x = xs - 4 + xl; y = y0 - 1 + m;
-                    const int ux = x - ORB_EDGE, uy = y - ORB_EDGE;
-                    const int xin = ux - __mul24((int)__umulhi((uint32_t)ux, g.wcell_magic), g.wcell);
-                    const int yin = uy - __mul24((int)__umulhi((uint32_t)uy, g.hcell_magic), g.hcell);
-                    // neighbours in another cell (or outside the detectable area, where the map is 0) do not count
-                    const bool l = xin > 0, r = xin < g.wcell - 1, u = yin > 0, d = yin < g.hcell - 1;
-                    // all eight reads are in range (the map has a one-pixel halo); issue them together
-                    const int nw_ = c[-FT_P - 1], n_ = c[-FT_P], ne_ = c[-FT_P + 1], w_ = c[-1], e_ = c[1];
-                    const int sw_ = c[FT_P - 1], s_ = c[FT_P], se_ = c[FT_P + 1];
-                    const int mu = max(max(l ? nw_ : 0, n_), r ? ne_ : 0);
-                    const int md = max(max(l ? sw_ : 0, s_), r ? se_ : 0);
-                    const int mc = max(l ? w_ : 0, r ? e_ : 0);
-                    keep = s > max(max(u ? mu : 0, d ? md : 0), mc);
+        const unsigned long long km = __ballot(keep);
+        if (keep) {
+            const int slot = nout + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0));
+            if (slot < FT_SEGCAP) out[slot] = make_uint2((uint32_t)(x - ORB_MINB) | ((uint32_t)(y - ORB_MINB) << 16), (uint32_t)s);
+        }
+        nout += __popcll(km);
+    };
+    const int nlist = s_nlist;                                 // the same for the whole workgroup
+    if (nlist <= FT_LIST) {
+        // the listed pixels, 64 at a time, the waves taking turns
+        for (int q = 64 * wv; q < nlist; q += 256) {
+            const bool have = q + lane < nlist;
+            const uint32_t e = have ? s_list[q + lane] : 0u;
+            nms_emit(have, (int)(e & 0xFF), (int)(e >> 8));
+        }
+    } else {
+        // dense texture: every wave finds the scored pixels of its 8 map rows 1+8*wv .. 8+8*wv in the
+        // map itself (a scored pixel is a non-zero byte) and compacts them through its queue
+        const int mh = 1 + 8 * wv;
+        uint32_t bits = 0;
+        if (lane >= 1 && lane <= 62) {                         // lanes 0 and 63 hold neighbour columns only
+            // rows outside the detectable area were never scored: their bytes are zero
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t v = *reinterpret_cast<const uint32_t*>(&s_map[(mh + j) * FT_P + 4 * lane]);
+                const uint32_t nz = (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;   // bit 7 of every non-zero byte
+                const uint32_t nib = ((nz >> 7) & 1u) | ((nz >> 14) & 2u) | ((nz >> 21) & 4u) | ((nz >> 28) & 8u);
+                bits |= nib << (4 * j);
+            }
+        }
+        if (__ballot(bits != 0)) {
+            const uint32_t cnt = __popc(bits);
+            const uint32_t incl = wave_scan_incl(cnt);
+            const int total = (int)__shfl(incl, 63, 64);
+            const int first = (int)(incl - cnt);
+            for (int wb = 0; wb < total; wb += FT_QUEUE) {
+                if (total <= FT_QUEUE) fast_fill_queue<false>(bits, first, 0, (uint32_t)lane << 5, queue);
+                else fast_fill_queue<true>(bits, first - wb, 0, (uint32_t)lane << 5, queue);
+                const int nw = min(FT_QUEUE, total - wb);
+                for (int q = 0; q < nw; q += 64) {
+                    const bool have = q + lane < nw;
+                    const uint32_t e = have ? queue[q + lane] : 0u;       // lane << 5 | 4 * row + pixel
+                    nms_emit(have, (int)((e >> 3) & 0xFC) + (int)(e & 3), mh + (int)((e >> 2) & 7));
                 }
-                const unsigned long long km = __ballot(keep);
-                if (keep) {
-                    const int slot = nout + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0));
-                    if (slot < FT_SEGCAP) out[slot] = make_uint2((uint32_t)(x - ORB_MINB) | ((uint32_t)(y - ORB_MINB) << 16), (uint32_t)s);
-                }
-                nout += __popcll(km);
             }
         }
     }
