@@ -18,6 +18,7 @@
 #define ORB_EDGE 19           // EDGE_THRESHOLD (src/ORBextractor.cc:74)
 #define ORB_MINB 16           // minBorderX/Y = EDGE_THRESHOLD-3 (src/ORBextractor.cc:773)
 #define ORB_MAX_LEVELS 16
+#define ORB_HP_ITEMS 384      // 6 trips of a wave
 #define ORB_DEAD_LABEL 0x3FFFFFu   // candidate dropped by the per-cell threshold rule (22-bit label field)
 
 struct RsTab {                // one bilinear tap pair of cv::resize (8 bytes)
@@ -67,6 +68,10 @@ struct PlanDev {
     // Byte weights of the orientation disc, one row of 32 bytes per |v| (byte i <-> u = i - 15):
     // words 0..7 hold 1 where |u| <= umax[|v|], words 8..15 hold u + 15 there; 0 elsewhere.
     uint32_t disc_w[16][16];
+    // Work items of the descriptor kernel's horizontal blur pass: row << 8 | first column (4 sums per
+    // item) of the 45 x 40 grid of row sums, only where a rotated test point can ever need them
+    // (the pattern lies inside a circle of radius sqrt(338)); padded with repeats to ORB_HP_ITEMS.
+    uint16_t hp_items[ORB_HP_ITEMS];
     LevelGeom lv[ORB_MAX_LEVELS];
 };
 

@@ -843,14 +843,15 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     // disc weights of this lane's row for the orientation step below (loaded early)
     const uint4* dwp = reinterpret_cast<const uint4*>(plan->disc_w[lane < 31 ? (lane < 15 ? 15 - lane : lane - 15) : 0]);
     const uint4 dw0 = dwp[0], dw1 = dwp[1], dw2 = dwp[2], dw3 = dwp[3];
-    // (16 lanes per row, 13 of them active, 4 rows per trip: addresses advance by a constant)
+    // (16 lanes per row, 13 of them active, 4 rows per trip: addresses advance by a constant; rows
+    // 0 and 44 are never read: the moments use rows 7..37 and the blur rows 1..43)
     {
-        const int sr = lane >> 4, sc = lane & 15;
+        const int sr = 1 + (lane >> 4), sc = lane & 15;
         uint32_t goff = (uint32_t)((ky - 22 + ORB_OY + sr) * g.pitch + colA + sc * 4);   // a plane is far below 4 GB
         uint8_t* dst = &raw[sr * DS_RAW_P + sc * 4];
         if (sc < 13) {
 #pragma unroll
-            for (int p = 0; p < 12; p++) {
+            for (int p = 0; p < 11; p++) {
                 if (4 * p + sr < 45) {
                     const uint32_t v = *reinterpret_cast<const uint32_t*>(P + goff);
                     *reinterpret_cast<uint32_t*>(dst + p * 4 * DS_RAW_P) = v;
@@ -893,19 +894,23 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     const uint32_t tap_lo = (uint32_t)t3 | ((uint32_t)t2 << 8) | ((uint32_t)t1 << 16) | ((uint32_t)t0 << 24);
     const uint32_t tap_hi = (uint32_t)t1 | ((uint32_t)t2 << 8) | ((uint32_t)t3 << 16);
     uint16_t* hp = s_hp[wv];
-    int hr = lane / 10, hc = lane - hr * 10;                   // item t = 10 * hr + hc; t += 64 <=> (hr, hc) += (6, 4)
-    for (int t = lane; t < 45 * 10; t += 64, hr += hc >= 6 ? 7 : 6, hc += hc >= 6 ? -6 : 4) {
-        const int r = hr, c = hc * 4;                          // sums c..c+3 (column 39 is padding)
+    // (only the items a rotated test point can need: see PlanDev::hp_items)
+    uint32_t items[ORB_HP_ITEMS / 64];
+#pragma unroll
+    for (int k = 0; k < ORB_HP_ITEMS / 64; k++) items[k] = plan->hp_items[64 * k + lane];
+#pragma unroll
+    for (int k = 0; k < ORB_HP_ITEMS / 64; k++) {
+        const int r = (int)(items[k] >> 8), c = (int)(items[k] & 0xFF);   // sums c..c+3 of row r (column 39 is padding)
         const uint32_t* rw = reinterpret_cast<const uint32_t*>(&raw[r * DS_RAW_P + c]);
         const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2], d3 = rw[3];
         const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, off), e1 = __builtin_amdgcn_alignbyte(d2, d1, off),
                        e2 = __builtin_amdgcn_alignbyte(d3, d2, off);          // bytes off+c .. off+c+11
         uint32_t acc[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t lo = k ? __builtin_amdgcn_alignbyte(e1, e0, k) : e0;   // taps at c+k .. c+k+3
-            const uint32_t hi = k ? __builtin_amdgcn_alignbyte(e2, e1, k) : e1;   // taps at c+k+4 .. c+k+6
-            acc[k] = __builtin_amdgcn_udot4(lo, tap_lo, __builtin_amdgcn_udot4(hi, tap_hi, 0u, false), false);
+        for (int q = 0; q < 4; q++) {
+            const uint32_t lo = q ? __builtin_amdgcn_alignbyte(e1, e0, q) : e0;   // taps at c+q .. c+q+3
+            const uint32_t hi = q ? __builtin_amdgcn_alignbyte(e2, e1, q) : e1;   // taps at c+q+4 .. c+q+6
+            acc[q] = __builtin_amdgcn_udot4(lo, tap_lo, __builtin_amdgcn_udot4(hi, tap_hi, 0u, false), false);
         }
         *reinterpret_cast<uint2*>(&hp[r * DS_HP_P + c]) = make_uint2(acc[0] | (acc[1] << 16), acc[2] | (acc[3] << 16));
     }

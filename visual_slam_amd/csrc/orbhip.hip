@@ -187,6 +187,30 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
             P.disc_w[a][i >> 2] |= 1u << (8 * (i & 3));
             P.disc_w[a][8 + (i >> 2)] |= (uint32_t)(u + 15) << (8 * (i & 3));
         }
+    {
+        // Rotated test points keep their distance from the keypoint (at most sqrt(338) for this
+        // pattern) and are rounded to the nearest pixel: a point on row ry has |rx| <= 0.5 +
+        // sqrt(R^2 - (|ry| - 0.5)^2), and the vertical 7-tap pass at (rx, ry) reads the row sums of
+        // rows ry-3 .. ry+3 at column rx. Row / column index of the sums = offset + 22 / + 19.
+        static const signed char pat[1024] = {
+#include "../../include/orb_pattern_31.inc"
+        };
+        int r2 = 0;
+        for (int i = 0; i < 512; i++) r2 = std::max(r2, pat[2 * i] * pat[2 * i] + pat[2 * i + 1] * pat[2 * i + 1]);
+        const double R = std::sqrt((double)r2) + 1e-3;
+        const int ry_max = (int)std::floor(R + 0.5);
+        int n = 0;
+        for (int dy = -ry_max - 3; dy <= ry_max + 3; dy++) {
+            const int ry = std::max(std::abs(dy) - 3, 0);
+            const double t = R * R - std::max(ry - 0.5, 0.0) * std::max(ry - 0.5, 0.0);
+            if (t < 0 || dy + 22 < 0 || dy + 22 > 44) continue;
+            const int m = std::min((int)std::floor(0.5 + std::sqrt(t)), 19);
+            for (int g = (19 - m) >> 2; g <= std::min((19 + m) >> 2, 9); g++)
+                if (n < ORB_HP_ITEMS) P.hp_items[n++] = (uint16_t)(((dy + 22) << 8) | (4 * g));
+                else { e->err = "internal: blur work list overflow"; return ORBHIP_ERR_ARG; }
+        }
+        for (int i = n; i < ORB_HP_ITEMS; i++) P.hp_items[i] = P.hp_items[i - n];   // repeats write the same values again
+    }
     size_t pyr_off = 0, keys_off = 0, seg_off = 0;
     int segc_off = 0, kp_off = 0, tab_off = 0;
     size_t max_qt_words = 0;
