@@ -72,6 +72,11 @@ struct PlanDev {
     // item) of the 45 x 40 grid of row sums, only where a rotated test point can ever need them
     // (the pattern lies inside a circle of radius sqrt(338)); padded with repeats to ORB_HP_ITEMS.
     uint16_t hp_items[ORB_HP_ITEMS];
+    // k_fast handles all levels in one launch: workgroups [fast_cum[l] * frames, fast_cum[l+1] * frames)
+    // belong to level l (fast_cum = running sum of tiles per frame); magics for the divisions by the
+    // tiles per frame and the tiles per row of a level (grid_magic)
+    uint32_t fast_cum[ORB_MAX_LEVELS + 1];
+    uint32_t fast_tiles_magic[ORB_MAX_LEVELS], fast_ntx_magic[ORB_MAX_LEVELS];
     LevelGeom lv[ORB_MAX_LEVELS];
 };
 
@@ -82,25 +87,20 @@ struct LevelKp {              // keypoint of one level after the quadtree, level
 };
 
 // Division of a workgroup index by a grid extent d through a multiply: m = ceil(2^32 / d) (0 for
-// d == 1) gives n / d == umulhi(n, m) whenever n * d < 2^32, which holds for every grid here
-// (n < 2^24 workgroups, d < 2^8 tiles per row or column).
+// d == 1: the quotient is n itself) gives n / d == umulhi(n, m) whenever n * d < 2^32; the host
+// checks that bound for the grids it launches.
 static inline unsigned grid_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
 
 #ifdef __HIPCC__
 // Workgroups are dealt to the 8 XCDs (each with its own L2) round-robin in dispatch order, so
 // tiles that are neighbours in the image would land on different L2s and each fetch the rows and
 // cache lines they share from memory again. This remap gives every group of workgroups that
-// share an XCD a contiguous range of the (x, y, z) grid instead (x fastest). It is a bijection of
-// the grid for any size; a wrong guess about placement costs speed, never correctness.
-// mx / my: grid_magic(gridDim.x / .y) from the host, so that the remap is a few scalar multiplies.
-__device__ __forceinline__ void xcd_tile(unsigned mx, unsigned my, int& bx, int& by, int& bz) {
-    const unsigned gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
-    const unsigned orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-    const unsigned q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    const unsigned t = mx ? __umulhi(id, mx) : id;
-    bx = (int)(id - t * gx);
-    bz = (int)(my ? __umulhi(t, my) : t);
-    by = (int)(t - (unsigned)bz * gy);
+// share an XCD a contiguous part of a range of `n` consecutive workgroups instead (`i` = position
+// inside the range; the XCD of a workgroup is its dispatch index modulo 8, so positions that are
+// equal modulo 8 share one wherever the range starts). It is a bijection of
+// the range for any size; a wrong guess about placement costs speed, never correctness.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned i, unsigned n) {
+    const unsigned q = n >> 3, r = n & 7, xcd = i & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (i >> 3);
 }
 #endif

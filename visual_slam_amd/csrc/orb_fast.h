@@ -230,12 +230,12 @@ __device__ __forceinline__ void fast_score_queue2(const uint16_t* queue, int n, 
                      lane, list, nlist);
 }
 
-// Grid: (tiles in x, tiles in y, frames). Output: segment (tile, wave) of FT_SEGCAP entries
+// Grid: one dimension, all tiles of all levels of all frames (level-major, then frame, tile row,
+// tile column: the large levels start first). Output: segment (tile, wave) of FT_SEGCAP entries
 // {x | y << 16 (relative to the detection window origin (16,16)), score} and its entry count.
-__global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, LevelGeom g, int min_th,
-                                              unsigned long long seg_per_frame, int segc_per_frame,
+__global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, const PlanDev* __restrict__ plan, int frames,
                                               uint2* __restrict__ seg, int* __restrict__ seg_count,
-                                              int* __restrict__ status, unsigned magic_x, unsigned magic_y) {
+                                              int* __restrict__ status) {
     __shared__ __align__(16) uint8_t s_map[FT_MAP_ROWS * FT_P];
     __shared__ __align__(16) uint8_t s_img[FT_IMG_ROWS * FT_P];
     __shared__ uint16_t s_queue[4][FT_QUEUE];
@@ -244,8 +244,23 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: row bookkeeping runs on the scalar unit
-    int bx, by, f;
-    xcd_tile(magic_x, magic_y, bx, by, f);                     // neighbouring tiles (shared halo rows / lines) share an L2
+    // which tile: everything here is uniform over the workgroup (scalar unit)
+    // The levels take consecutive ranges of the dispatch order; inside its level's range a workgroup
+    // is remapped so that neighbouring tiles (shared halo rows / lines) share an L2 and every level
+    // is spread over all XCDs (tiles of different levels do not cost the same).
+    const unsigned id = blockIdx.x;
+    int level = 0;
+    while (level + 1 < plan->nlevels && id >= plan->fast_cum[level + 1] * (unsigned)frames) level++;
+    const LevelGeom g = plan->lv[level];
+    const unsigned rem = xcd_contiguous(id - plan->fast_cum[level] * (unsigned)frames, (unsigned)(g.ntx * g.nty * frames));
+    const unsigned mt = plan->fast_tiles_magic[level], mx = plan->fast_ntx_magic[level];
+    const int f = (int)(mt ? __umulhi(rem, mt) : rem);
+    const unsigned t = rem - (unsigned)f * (unsigned)(g.ntx * g.nty);
+    const int by = (int)(mx ? __umulhi(t, mx) : t);
+    const int bx = (int)(t - (unsigned)by * (unsigned)g.ntx);
+    const int min_th = plan->min_th;
+    const unsigned long long seg_per_frame = plan->seg_per_frame;
+    const int segc_per_frame = plan->segc_per_frame;
     const int xs = ORB_MINB + FT_COLS * bx;                    // level x of the tile's first output column
     const int y0 = ORB_EDGE + FT_ROWS * by;                    // level y of the tile's first row
     const int x_hi = g.w - ORB_EDGE, y_hi = g.h - ORB_EDGE;    // detectable area [19, x_hi) x [19, y_hi)
@@ -382,7 +397,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, L
     __syncthreads();                                           // all scores of the tile are in the map
 
     // ---- non-maximum suppression inside the cell and emission
-    const int segi = (by * (int)gridDim.x + bx) * 4 + wv;
+    const int segi = (by * g.ntx + bx) * 4 + wv;
     uint2* out = seg + (size_t)f * seg_per_frame + g.seg_off + (size_t)segi * FT_SEGCAP;
     int nout = 0;
     // One scored output pixel per lane: tile column xl, map row m. Neighbours in another cell (or

@@ -262,6 +262,18 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
         g.xtab_off = tab_off; tab_off += (ORB_OX + g.w + ORB_EDGE + 3) / 4 * 4;
         g.ytab_off = tab_off; tab_off += (g.rows + 1) & ~1;
     }
+    P.fast_cum[0] = 0;
+    for (int l = 0; l < nl; l++) {
+        const unsigned tiles = (unsigned)(P.lv[l].ntx * P.lv[l].nty);
+        P.fast_cum[l + 1] = P.fast_cum[l] + tiles;
+        P.fast_tiles_magic[l] = grid_magic(tiles);
+        P.fast_ntx_magic[l] = grid_magic((unsigned)P.lv[l].ntx);
+        // the magic divisions in k_fast are exact for n * d < 2^32
+        if ((unsigned long long)tiles * frames * std::max(tiles, 1u) >= (1ull << 32)) {
+            e->err = "too many FAST tiles per pass"; return ORBHIP_ERR_GEOMETRY;
+        }
+    }
+    if ((unsigned long long)P.fast_cum[nl] * frames >= (1ull << 31)) { e->err = "too many FAST tiles per pass"; return ORBHIP_ERR_GEOMETRY; }
     P.seg_per_frame = std::max(seg_off, (size_t)1);
     P.segc_per_frame = std::max(segc_off, 1);
     P.keys_per_frame = keys_off;
@@ -370,13 +382,10 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
         hipLaunchKernelGGL(k_resize, grid, blk2, 0, s, W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g,
                            e->d_tabs, ndw);
     }
-    for (int l = 0; l < nl; l++) {
-        const LevelGeom& g = P.lv[l];
-        if (g.ncols < 1) continue;
+    if (P.fast_cum[nl] > 0) {                                  // all levels in one launch
         SpanGuard t(e, s, KC_FAST);
-        hipLaunchKernelGGL(k_fast, dim3(g.ntx, g.nty, frames), dim3(256), 0, s,
-                           W.d_pyr, g, P.min_th, P.seg_per_frame, P.segc_per_frame,
-                           W.d_seg, W.d_seg_count, e->d_status, grid_magic(g.ntx), grid_magic(g.nty));
+        hipLaunchKernelGGL(k_fast, dim3(P.fast_cum[nl] * (unsigned)frames), dim3(256), 0, s,
+                           W.d_pyr, e->d_plan, frames, W.d_seg, W.d_seg_count, e->d_status);
     }
     {
         SpanGuard t(e, s, KC_QUADTREE);
