@@ -398,7 +398,9 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
     __shared__ uint32_t s_red[4];
     __shared__ int s_nkeys;
     const int tid = threadIdx.x;
-    const int level = blockIdx.x, f = blockIdx.y;
+    // Grid (frames, levels): consecutive workgroups, which are dealt to the 8 XCDs in turn, hold the
+    // same level of different frames (the levels differ a lot in cost), the large levels first.
+    const int f = blockIdx.x, level = blockIdx.y;
     const LevelGeom g = plan->lv[level];
     const int M = g.node_cap;
     const int N = g.quota;

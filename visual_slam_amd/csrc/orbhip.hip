@@ -389,7 +389,7 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
     }
     {
         SpanGuard t(e, s, KC_QUADTREE);
-        hipLaunchKernelGGL(k_quadtree, dim3(nl, frames), dim3(QT_THREADS), e->qt_lds, s,
+        hipLaunchKernelGGL(k_quadtree, dim3(frames, nl), dim3(QT_THREADS), e->qt_lds, s,
                            e->d_plan, W.d_seg, W.d_seg_count, W.d_keys, W.d_key_count, W.d_lvl_kp, W.d_lvl_cnt,
                            e->d_status);
     }
