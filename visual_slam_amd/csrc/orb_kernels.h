@@ -809,13 +809,21 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
                                                   const int* __restrict__ lvl_cnt,
                                                   float* __restrict__ out_kp,   // 7 floats per keypoint
                                                   uint8_t* __restrict__ out_desc, int* __restrict__ out_count,
-                                                  int cap, int frame0, int* __restrict__ status) {
+                                                  int cap, int frame0, int* __restrict__ status,
+                                                  int frames, int ngroups, unsigned ngroups8_magic) {
     __shared__ __align__(16) uint8_t s_raw[4][DS_RAW_BYTES];
     __shared__ __align__(16) uint16_t s_hp[4][DS_HP_ENTRIES];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // everything per keypoint is wave-uniform
-    const int f = blockIdx.y;
-    const int idx = blockIdx.x * 4 + wv;
+    // One-dimensional grid: 8 consecutive workgroups (one per XCD, each with its own L2) take the
+    // same group of 4 keypoints in 8 consecutive frames, then the next group of the same frames:
+    // an XCD works through one frame at a time, whose pyramid then stays in its L2.
+    const unsigned id = blockIdx.x;
+    const unsigned fb = ngroups8_magic ? __umulhi(id, ngroups8_magic) : id;    // id / (8 * ngroups)
+    const unsigned within = id - fb * (unsigned)(8 * ngroups);
+    const int f = (int)(fb * 8 + (within & 7));
+    if (f >= frames) return;
+    const int idx = (int)(within >> 3) * 4 + wv;
     const int nl = plan->nlevels;
     // locate (level, j) of output keypoint idx: levels are concatenated in order (src/ORBextractor.cc:1076-1104)
     int level = -1, j = idx, total = 0;

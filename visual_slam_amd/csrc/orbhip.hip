@@ -396,8 +396,12 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
     {
         SpanGuard t(e, s, KC_DESCRIBE);
         const int maxkp = std::min(cap, P.kp_per_frame);
-        hipLaunchKernelGGL(k_describe, dim3((maxkp + 3) / 4, frames), dim3(256), 0, s,
-                           e->d_plan, W.d_pyr, W.d_lvl_kp, W.d_lvl_cnt, d_kp, d_desc, d_counts, cap, frame0, e->d_status);
+        const int ngroups = (maxkp + 3) / 4;                  // 4 keypoints per workgroup
+        const unsigned nwg = (unsigned)ngroups * 8u * (unsigned)((frames + 7) / 8);
+        if ((unsigned long long)nwg * (8ull * ngroups) >= (1ull << 32)) { e->err = "too many keypoints per pass"; return ORBHIP_ERR_CAPACITY; }
+        hipLaunchKernelGGL(k_describe, dim3(nwg), dim3(256), 0, s,
+                           e->d_plan, W.d_pyr, W.d_lvl_kp, W.d_lvl_cnt, d_kp, d_desc, d_counts, cap, frame0, e->d_status,
+                           frames, ngroups, grid_magic(8u * (unsigned)ngroups));
     }
     HIP_TRY(e, hipGetLastError());
     e->last_pass_frames = frames;
