@@ -17,7 +17,7 @@ name_col = "kernel_name" if "kernel_name" in ci else "name"
 agg = defaultdict(lambda: defaultdict(float))
 ndisp = defaultdict(set)
 for r in rows:
-    k = str(r[ci[name_col]]).split("(")[0]
+    k = str(r[ci[name_col]]).split("(")[0].replace("void ", "")
     if not k.startswith(prefix):
         continue
     agg[k][r[ci["counter_name"]]] += float(r[ci["value"]])

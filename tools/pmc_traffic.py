@@ -20,7 +20,7 @@ def per_kernel(db_path, counter):
     name_col = "kernel_name" if "kernel_name" in ci else "name"
     tot, disp = defaultdict(float), defaultdict(set)
     for r in cur.execute("select * from counters_collection"):
-        k = str(r[ci[name_col]]).split("(")[0]
+        k = str(r[ci[name_col]]).split("(")[0].replace("void ", "").split("<")[0]
         if not k.startswith("k_") or r[ci["counter_name"]] != counter:
             continue
         tot[k] += float(r[ci["value"]])

@@ -53,6 +53,7 @@ struct LevelGeom {
     float patch_size;         // (float)(int)(31 * mvScaleFactor[level])
     // resize tables
     int xtab_off, ytab_off;   // offsets (entries) into the RsTab buffer
+    int rs_narrow;            // 1: the taps of every 4-pixel group of this level span at most 8 source bytes
 };
 
 struct PlanDev {

@@ -214,24 +214,30 @@ __global__ __launch_bounds__(256) void k_level0_remap(const uint8_t* __restrict_
 // A lane produces 4 adjacent pixels of RS_RPT consecutive rows. The source bytes of the 4 pixels
 // lie inside 12 bytes starting at a 4-aligned offset (checked on the host), so one dwordx3 load
 // per source row feeds them; v_perm_b32 pulls the two taps of a pixel into 16-bit halves and
-// v_dot2_i32_i16 applies the two 11-bit weights. Consecutive output rows usually share a source
-// row; its horizontal pass is reused. A wave is short, so its time is set by memory latency: all
-// source rows of its RS_RPT output rows are requested before any arithmetic starts.
+// v_dot2_u32_u16 applies the two 11-bit weights. NARROW (every level of a pyramid whose steps
+// shrink by less than 2: the host checks that the 4 pixels' taps span at most 8 bytes): two
+// v_alignbyte_b32 first bring the leftmost source column to byte 0, so that every tap pair is one
+// v_perm_b32 of the same two registers; otherwise each pixel selects its register pair first.
+// Consecutive output rows usually share a source row; its horizontal pass is reused. All
+// source rows of the RS_RPT output rows of a wave are requested before any arithmetic starts.
 // ------------------------------------------------------------------------------------------------
 #define RS_RPT 8
 
 struct __attribute__((packed, aligned(4))) Row12 { uint32_t a, b, c; };
+typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 
 // src / dst: plane of frame 0 of the source / destination level (different levels never overlap,
 // which lets the loads of all rows be issued before the first store).
+template <bool NARROW>
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                 LevelGeom gs, LevelGeom gd, const RsTab* __restrict__ tabs, int ndw) {
-    // (An XCD-aware tile order cuts the fetched bytes by a third here but measures 6 % slower: the
-    // kernel is bound by latency, not by bandwidth. Plain dispatch order it is.)
-    const int c4 = blockIdx.x * 64 + threadIdx.x;
+    // (An XCD-aware tile order cuts the bytes the L2s fetch by a third here but measures 6 % slower,
+    // with the vector work of either variant: in plain dispatch order the XCDs stream through the same
+    // region together and the cache behind the L2s absorbs the rows they share. Plain order it is.)
+    const int bx = blockIdx.x, by = blockIdx.y, f = blockIdx.z;
+    const int c4 = bx * 64 + threadIdx.x;
     // a wave = one value of threadIdx.y: rows, their tap entries and row addresses are wave-uniform
-    const int r0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * RS_RPT;
-    const int f = blockIdx.z;
+    const int r0 = (by * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * RS_RPT;
     if (c4 >= ndw || r0 >= gd.rows) return;
     // x side: the same for every row
     const uint4* tx = reinterpret_cast<const uint4*>(tabs + gd.xtab_off + c4 * 4);
@@ -239,14 +245,16 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     const uint32_t pos[4] = {ta.x, ta.z, tb.x, tb.z};          // s0 | s1 << 16
     const uint32_t wgt[4] = {ta.y, ta.w, tb.y, tb.w};          // a0 | a1 << 16
     const int s00 = pos[0] & 0xFFFF, s01 = pos[1] & 0xFFFF, s02 = pos[2] & 0xFFFF, s03 = pos[3] & 0xFFFF;
-    const int base = min(min(s00, s01), min(s02, s03)) & ~3;
+    const int smin = min(min(s00, s01), min(s02, s03));
+    const int base = smin & ~3;
+    const uint32_t sh = (uint32_t)smin & 3;                    // NARROW: the loaded bytes are shifted so that byte 0 is column smin
     uint32_t sel[4];
     bool hi[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int o = (int)(pos[i] & 0xFFFF) - base;           // 0 .. 10
-        hi[i] = o >= 4;
-        const uint32_t idx = (uint32_t)(hi[i] ? o - 4 : o);     // byte index inside the chosen dword pair
+        const int o = (int)(pos[i] & 0xFFFF) - (NARROW ? smin : base);   // NARROW: 0 .. 6, else 0 .. 10
+        hi[i] = !NARROW && o >= 4;
+        const uint32_t idx = (uint32_t)(hi[i] ? o - 4 : o);     // byte index inside the (chosen) dword pair
         sel[i] = idx | (0x0Cu << 8) | ((idx + 1) << 16) | (0x0Cu << 24);
     }
     // uniform plane pointers + 32-bit (row, lane) offsets: a plane is far below 4 GB
@@ -266,19 +274,22 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
             va[k] = *reinterpret_cast<const Row12*>(S + ((uint32_t)((int)ty[k].s0 * gs.pitch) + lbase));
         vb[k] = *reinterpret_cast<const Row12*>(S + ((uint32_t)((int)ty[k].s1 * gs.pitch) + lbase));
     }
-    auto hpass = [&](const Row12& v, int (&h)[4]) {
+    auto hpass = [&](const Row12& v, uint32_t (&h)[4]) {
+        const uint32_t lo = NARROW ? __builtin_amdgcn_alignbyte(v.b, v.a, sh) : 0u;
+        const uint32_t up = NARROW ? __builtin_amdgcn_alignbyte(v.c, v.b, sh) : 0u;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t p = __builtin_amdgcn_perm(hi[i] ? v.c : v.b, hi[i] ? v.b : v.a, sel[i]);   // tap0 | tap1 << 16
-            h[i] = __builtin_amdgcn_sdot2(u2v(p), u2v(wgt[i]), 0, false) >> 4;
+            const uint32_t p = NARROW ? __builtin_amdgcn_perm(up, lo, sel[i])
+                                      : __builtin_amdgcn_perm(hi[i] ? v.c : v.b, hi[i] ? v.b : v.a, sel[i]);   // tap0 | tap1 << 16
+            h[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(v2us, p), __builtin_bit_cast(v2us, wgt[i]), 0u, false) >> 4;
         }
     };
-    int hprev[4] = {0, 0, 0, 0};
+    uint32_t hprev[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < RS_RPT; k++) {
         const int r = r0 + k;
         if (r >= gd.rows) break;
-        int h0[4], h1[4];
+        uint32_t h0[4], h1[4];
         if (k > 0 && ty[k].s0 == ty[k - 1].s1) {
 #pragma unroll
             for (int i = 0; i < 4; i++) h0[i] = hprev[i];
@@ -286,14 +297,19 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
             hpass(va[k], h0);
         }
         hpass(vb[k], h1);
-        const int b0 = ty[k].a0, b1 = ty[k].a1;
+        const uint32_t b0 = (uint32_t)ty[k].a0, b1 = (uint32_t)ty[k].a1;   // weights are never negative
         uint32_t out = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             hprev[i] = h1[i];
-            // 11-bit weight x 15-bit row value: the full-rate 24-bit multiply is exact
-            const int v = ((__mul24(b0, h0[i]) >> 16) + (__mul24(b1, h1[i]) >> 16) + 2) >> 2;     // <= 255 by construction
-            out |= (uint32_t)v << (8 * i);
+            // 11-bit weight x 15-bit row value: the full-rate 24-bit multiply is exact.
+            // ((p0 >> 16) + (p1 >> 16) + 2) >> 2 with the 2 added as 2 << 16 before the shift of p0; the
+            // sum of the two upper halves is one add with 16-bit operand selects
+            const uint32_t p0 = __umul24(b0, h0[i]) + 0x20000u, p1 = __umul24(b1, h1[i]);
+            uint32_t sum;
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1"
+                : "=v"(sum) : "v"(p0), "v"(p1));
+            out |= (sum >> 2) << (8 * i);                      // <= 255 by construction
         }
         *reinterpret_cast<uint32_t*>(D + ((uint32_t)(r * gd.pitch) + 4u * (uint32_t)c4)) = out;
     }

@@ -290,12 +290,16 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
         const int ncol = (ORB_OX + g.w + ORB_EDGE + 3) / 4 * 4;
         for (int c = 0; c < ncol; c++) tabs[g.xtab_off + c] = xt[reflect101_host(c - ORB_OX, g.w)];
         for (int r = 0; r < g.rows; r++) tabs[g.ytab_off + r] = yt[reflect101_host(r - ORB_OY, g.h)];
-        // k_resize feeds the 4 pixels of a lane from one 12-byte load at a 4-aligned source offset
+        // k_resize feeds the 4 pixels of a lane from one 12-byte load at a 4-aligned source offset;
+        // its shorter variant needs their taps (two bytes each) inside 8 bytes from the leftmost one
+        int narrow = 1;
         for (int c = 0; c < ncol; c += 4) {
             int lo = 1 << 30, hi = 0;
             for (int i = 0; i < 4; i++) { lo = std::min(lo, (int)tabs[g.xtab_off + c + i].s0); hi = std::max(hi, (int)tabs[g.xtab_off + c + i].s0); }
             if (hi + 1 - (lo & ~3) > 11) { e->err = "scale factor too large for the resize kernel (must be <= 2)"; return ORBHIP_ERR_ARG; }
+            if (hi + 1 - lo > 7) narrow = 0;
         }
+        P.lv[l].rs_narrow = narrow;
     }
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipMalloc(&e->d_plan, sizeof(PlanDev)));
@@ -379,8 +383,12 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
         const LevelGeom& g = P.lv[l];
         const int ndw = (ORB_OX + g.w + ORB_EDGE + 3) / 4;
         const dim3 grid((ndw + 63) / 64, (g.rows + 4 * RS_RPT - 1) / (4 * RS_RPT), frames);
-        hipLaunchKernelGGL(k_resize, grid, blk2, 0, s, W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g,
-                           e->d_tabs, ndw);
+        if (g.rs_narrow)
+            hipLaunchKernelGGL(k_resize<true>, grid, blk2, 0, s, W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g,
+                               e->d_tabs, ndw);
+        else
+            hipLaunchKernelGGL(k_resize<false>, grid, blk2, 0, s, W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g,
+                               e->d_tabs, ndw);
     }
     if (P.fast_cum[nl] > 0) {                                  // all levels in one launch
         SpanGuard t(e, s, KC_FAST);
