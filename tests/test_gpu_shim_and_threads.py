@@ -52,8 +52,9 @@ def test_two_instances_on_two_threads_like_stereo():
 
 @pytest.mark.gpu
 def test_two_passes_in_flight_give_the_same_results():
-    """ORBHIP_LANES=2 splits a large batch into passes on two internal streams (read at handle
-    creation, so it runs in a child process); the outputs must equal the single-stream ones."""
+    """ORBHIP_LANES=2 splits a large batch into passes on two internal streams, ORBHIP_OVERLAP=1 runs
+    level 0's FAST beside the resize chain on a second stream (both read at handle creation, so they
+    run in child processes); the outputs must equal the single-stream ones."""
     import os
     import subprocess
     import sys
@@ -72,12 +73,13 @@ def test_two_passes_in_flight_give_the_same_results():
     ) % str(root)
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
-        for lanes in ("1", "2"):
-            path = os.path.join(tmp, "lanes%s.npz" % lanes)
-            env = dict(os.environ, ORBHIP_LANES=lanes)
+        for lanes, overlap in (("1", "0"), ("2", "0"), ("1", "1"), ("2", "1")):
+            path = os.path.join(tmp, "lanes%s_%s.npz" % (lanes, overlap))
+            env = dict(os.environ, ORBHIP_LANES=lanes, ORBHIP_OVERLAP=overlap)
             subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=240)
             with np.load(path) as z:
-                out[lanes] = {k: z[k] for k in z.files}
-    assert out["1"]["n"].sum() > 80 * 100
-    for k in ("n", "kp", "desc"):
-        assert np.array_equal(out["1"][k], out["2"][k]), k
+                out[lanes + overlap] = {k: z[k] for k in z.files}
+    assert out["10"]["n"].sum() > 80 * 100
+    for mode in ("20", "11", "21"):
+        for k in ("n", "kp", "desc"):
+            assert np.array_equal(out["10"][k], out[mode][k]), (mode, k)

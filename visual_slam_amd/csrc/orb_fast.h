@@ -235,7 +235,7 @@ __device__ __forceinline__ void fast_score_queue2(const uint16_t* queue, int n, 
 // {x | y << 16 (relative to the detection window origin (16,16)), score} and its entry count.
 __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, const PlanDev* __restrict__ plan, int frames,
                                               uint2* __restrict__ seg, int* __restrict__ seg_count,
-                                              int* __restrict__ status) {
+                                              int* __restrict__ status, unsigned id_base) {
     __shared__ __align__(16) uint8_t s_map[FT_MAP_ROWS * FT_P];
     __shared__ __align__(16) uint8_t s_img[FT_IMG_ROWS * FT_P];
     __shared__ uint16_t s_queue[4][FT_QUEUE];
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
     // The levels take consecutive ranges of the dispatch order; inside its level's range a workgroup
     // is remapped so that neighbouring tiles (shared halo rows / lines) share an L2 and every level
     // is spread over all XCDs (tiles of different levels do not cost the same).
-    const unsigned id = blockIdx.x;
+    const unsigned id = id_base + blockIdx.x;                  // a launch may cover a sub-range of the levels
     int level = 0;
     while (level + 1 < plan->nlevels && id >= plan->fast_cum[level + 1] * (unsigned)frames) level++;
     const LevelGeom g = plan->lv[level];

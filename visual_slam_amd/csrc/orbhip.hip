@@ -71,6 +71,9 @@ struct orbhip_extractor {
     int plan_lanes = 0;            // workspaces allocated for the current plan
     int max_lanes = 1;             // ORBHIP_LANES=2..4: that many passes of a large batch in flight (a few % more throughput)
     hipEvent_t ev_fork = nullptr;
+    int overlap = 0;               // ORBHIP_OVERLAP=1: FAST of level 0 runs beside the resize chain on aux_stream
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_l0 = nullptr, ev_f0 = nullptr;
     hipEvent_t ev_order = nullptr;   // orders work of another instance (stereo matching) against this one's stream
     hipStream_t last_stream = nullptr;   // stream of the last batch call
     int* d_status = nullptr;       // bit0 candidate overflow, bit1 output capacity
@@ -378,6 +381,19 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
                                d_imgs, row_stride, frame_stride, W.d_pyr, g, n16, n16, n16);
         }
     }
+    // FAST is bound by vector issue, the resize chain by memory: with `overlap` level 0's FAST runs on
+    // a second stream beside the chain and the remaining levels follow on the main stream
+    const unsigned split = (e->overlap && nl > 1) ? P.fast_cum[1] * (unsigned)frames : 0u;
+    if (split) {
+        HIP_TRY(e, hipEventRecord(e->ev_l0, s));
+        HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->ev_l0, 0));
+        {
+            SpanGuard t(e, e->aux_stream, KC_FAST);
+            hipLaunchKernelGGL(k_fast, dim3(split), dim3(256), 0, e->aux_stream,
+                               W.d_pyr, e->d_plan, frames, W.d_seg, W.d_seg_count, e->d_status, 0u);
+        }
+        HIP_TRY(e, hipEventRecord(e->ev_f0, e->aux_stream));
+    }
     for (int l = 1; l < nl; l++) {
         SpanGuard t(e, s, KC_RESIZE);
         const LevelGeom& g = P.lv[l];
@@ -390,11 +406,12 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
             hipLaunchKernelGGL(k_resize<false>, grid, blk2, 0, s, W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g,
                                e->d_tabs, ndw);
     }
-    if (P.fast_cum[nl] > 0) {                                  // all levels in one launch
+    if (P.fast_cum[nl] * (unsigned)frames > split) {           // all (remaining) levels in one launch
         SpanGuard t(e, s, KC_FAST);
-        hipLaunchKernelGGL(k_fast, dim3(P.fast_cum[nl] * (unsigned)frames), dim3(256), 0, s,
-                           W.d_pyr, e->d_plan, frames, W.d_seg, W.d_seg_count, e->d_status);
+        hipLaunchKernelGGL(k_fast, dim3(P.fast_cum[nl] * (unsigned)frames - split), dim3(256), 0, s,
+                           W.d_pyr, e->d_plan, frames, W.d_seg, W.d_seg_count, e->d_status, split);
     }
+    if (split) HIP_TRY(e, hipStreamWaitEvent(s, e->ev_f0, 0));
     {
         SpanGuard t(e, s, KC_QUADTREE);
         hipLaunchKernelGGL(k_quadtree, dim3(frames, nl), dim3(QT_THREADS), e->qt_lds, s,
@@ -494,13 +511,17 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
         delete e;
         return ORBHIP_ERR_HIP;
     }
-    bool ok = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess &&
+    bool ok = hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&e->ev_l0, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&e->ev_f0, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming) == hipSuccess;
     for (Workspace& w : e->ws)
         ok = ok && hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&w.done, hipEventDisableTiming) == hipSuccess;
     if (!ok) { orbhip_destroy(e); return ORBHIP_ERR_HIP; }
     if (const char* v = std::getenv("ORBHIP_LANES")) e->max_lanes = std::min(kLanes, std::max(1, std::atoi(v)));
+    if (const char* v = std::getenv("ORBHIP_OVERLAP")) e->overlap = std::atoi(v) != 0;
     *out = e;
     return ORBHIP_OK;
 }
@@ -523,6 +544,9 @@ int orbhip_destroy(orbhip_extractor* e) {
         if (w.done) (void)hipEventDestroy(w.done);
     }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_l0) (void)hipEventDestroy(e->ev_l0);
+    if (e->ev_f0) (void)hipEventDestroy(e->ev_f0);
+    if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
     if (e->ev_order) (void)hipEventDestroy(e->ev_order);
     delete e;
     return ORBHIP_OK;
