@@ -72,13 +72,21 @@ __global__ __launch_bounds__(256) void k_stereo_match(const PlanDev* __restrict_
                                                       const StKp* __restrict__ kp_r, const uint8_t* __restrict__ desc_r,
                                                       int cap, float mb, float mbf,
                                                       float* __restrict__ uright, float* __restrict__ depth,
-                                                      int* __restrict__ sad_out) {
+                                                      int* __restrict__ sad_out, int nframes, int ngroups,
+                                                      unsigned ngroups8_magic) {
     __shared__ int s_dist[4][12];
     __shared__ uint16_t s_cand[4][ST_CAND];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int f = blockIdx.y;
-    const int iL = blockIdx.x * 4 + wv;
+    // One-dimensional grid: 8 consecutive workgroups (one per XCD, each with its own L2) take the
+    // same group of 4 left keypoints in 8 consecutive pairs: an XCD stays with one pair at a time,
+    // whose two pyramids and right-image records then sit in its L2.
+    const unsigned id = blockIdx.x;
+    const unsigned fb = ngroups8_magic ? __umulhi(id, ngroups8_magic) : id;    // id / (8 * ngroups)
+    const unsigned within = id - fb * (unsigned)(8 * ngroups);
+    const int f = (int)(fb * 8 + (within & 7));
+    if (f >= nframes) return;
+    const int iL = (int)(within >> 3) * 4 + wv;
     const int nl = min(cnt_l[f], cap);
     if (iL >= nl) return;                                      // waves are independent: no workgroup barrier below
     const size_t o = (size_t)f * cap;

@@ -888,10 +888,14 @@ int orbhip_stereo_match_batch_device(orbhip_extractor* left, orbhip_extractor* r
     SpanGuard t(e, s, KC_STEREO);
     hipLaunchKernelGGL(k_stereo_prep, dim3(nframes), dim3(256), 0, s,
                        left->d_plan, reinterpret_cast<const StKp*>(d_kp_r), d_cnt_r, cap, nbins, e->d_st_rinfo, e->d_st_bins);
-    hipLaunchKernelGGL(k_stereo_match, dim3((cap + 3) / 4, nframes), dim3(256), 0, s,
+    const int ngroups = (cap + 3) / 4;                         // 4 left keypoints per workgroup
+    const unsigned nwg = (unsigned)ngroups * 8u * (unsigned)((nframes + 7) / 8);
+    if ((unsigned long long)nwg * (8ull * ngroups) >= (1ull << 32)) { e->err = "too many keypoints per pass"; return ORBHIP_ERR_CAPACITY; }
+    hipLaunchKernelGGL(k_stereo_match, dim3(nwg), dim3(256), 0, s,
                        left->d_plan, e->d_st_rinfo, e->d_st_bins, nbins, band, left->ws[left->last_ws].d_pyr, right->ws[right->last_ws].d_pyr,
                        reinterpret_cast<const StKp*>(d_kp_l), d_desc_l, d_cnt_l,
-                       reinterpret_cast<const StKp*>(d_kp_r), d_desc_r, cap, mb, mbf, d_uright, d_depth, e->d_st_sad);
+                       reinterpret_cast<const StKp*>(d_kp_r), d_desc_r, cap, mb, mbf, d_uright, d_depth, e->d_st_sad,
+                       nframes, ngroups, grid_magic(8u * (unsigned)ngroups));
     int* nm = d_nmatch;
     hipLaunchKernelGGL(k_stereo_median, dim3(nframes), dim3(256), 0, s, d_cnt_l, cap, e->d_st_sad, d_uright, d_depth,
                        nm ? nm : e->d_st_sad + (size_t)nframes * cap);
