@@ -70,6 +70,8 @@ def main():
         if len(k1) == 0 or len(k2) == 0:
             continue
         bounds = O.image_bounds(cam, w, h)
+        if not (bounds[1] > bounds[0] and bounds[3] > bounds[2]):
+            continue                                         # a distortion so strong that the frame folds over: no grid
         u1 = O.undistort_grid(cam, bounds, k1)[0]; u2 = O.undistort_grid(cam, bounds, k2)[0]
         Z = float(rng.uniform(2, 20))
         fx, fy, cx, cy = cam[:4]

@@ -132,20 +132,23 @@ __global__ __launch_bounds__(256) void k_level0_color(const uint8_t* __restrict_
 // unaligned 16-bit load. A pair that straddles the image edge is moved inside and its weights are
 // moved or cleared accordingly.
 // ------------------------------------------------------------------------------------------------
-#define RM_FR 4
+#define RM_FR 8
+
+struct __attribute__((packed, aligned(4))) Row12 { uint32_t a, b, c; };
 
 typedef unsigned short v2us_t __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void k_level0_remap(const uint8_t* __restrict__ src, size_t row_stride, size_t frame_stride,
                                                       int frames, const float* __restrict__ map_x,
                                                       const float* __restrict__ map_y, uint8_t* __restrict__ pyr,
-                                                      LevelGeom g, int ndw) {
+                                                      LevelGeom g, int ndw, int aligned4) {
     const int c4 = blockIdx.x * 64 + threadIdx.x;
     const int r = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int f0 = blockIdx.z * RM_FR;
     if (c4 >= ndw || r >= g.rows) return;
     const int y = reflect101(r - ORB_OY, g.h);
     uint32_t off[4], wa[4], wb[4];
+    int cxs[4], cys[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int x = min(max(reflect101(4 * c4 + j - ORB_OX, g.w), 0), g.w - 1);   // columns of the row padding: anything inside
@@ -171,36 +174,100 @@ __global__ __launch_bounds__(256) void k_level0_remap(const uint8_t* __restrict_
         else if (cy == sy - 1) { w10 = w00; w11 = w01; w00 = 0; w01 = 0; }
         else if (cy != sy) { w00 = w01 = w10 = w11 = 0; }
         off[j] = (uint32_t)cy * (uint32_t)row_stride + (uint32_t)cx;        // a frame is far below 4 GB
+        cxs[j] = cx; cys[j] = cy;
         wa[j] = w00 | (w01 << 16);
         wb[j] = w10 | (w11 << 16);
     }
     const int nf = min(RM_FR, frames - f0);
-    uint16_t lo[RM_FR][4], hi[RM_FR][4];
+    // Rectification maps move neighbours together: normally the taps of the 4 pixels lie within 8
+    // columns of 3 consecutive source rows, which three 8-byte loads per frame cover (instead of
+    // eight 2-byte ones). Pixel j then reads rows d, d+1 (d = 0 or 1) of the three, which is a
+    // weight pair per row with zeros for the row it does not use.
+    const int cx0 = min(min(cxs[0], cxs[1]), min(cxs[2], cxs[3])), cx1 = max(max(cxs[0], cxs[1]), max(cxs[2], cxs[3]));
+    const int cy0 = min(min(cys[0], cys[1]), min(cys[2], cys[3])), cy1 = max(max(cys[0], cys[1]), max(cys[2], cys[3]));
+    const int cxa = cx0 & ~3;                                  // dword-aligned loads: aligned4 says that the caller's rows are
+    const bool compact = aligned4 && cx1 - cx0 <= 6 && cy1 - cy0 <= 1 && cxa + 12 <= g.w;
+    if (__all(compact)) {
+        uint32_t sel[4], w0[4], w1[4], w2[4];
 #pragma unroll
-    for (int k = 0; k < RM_FR; k++) {
-        if (k < nf) {
-            const uint8_t* S = src + (size_t)(f0 + k) * frame_stride;
+        for (int j = 0; j < 4; j++) {
+            const uint32_t o = (uint32_t)(cxs[j] - cx0);      // 0 .. 6: bytes o, o+1 of the 8 loaded ones
+            sel[j] = o | (0x0Cu << 8) | ((o + 1) << 16) | (0x0Cu << 24);
+            const bool d = cys[j] != cy0;
+            w0[j] = d ? 0u : wa[j];
+            w1[j] = d ? wa[j] : wb[j];
+            w2[j] = d ? wb[j] : 0u;
+        }
+        const uint32_t o0 = (uint32_t)cy0 * (uint32_t)row_stride + (uint32_t)cxa;
+        const uint32_t o2 = (uint32_t)min(cy0 + 2, g.h - 1) * (uint32_t)row_stride + (uint32_t)cxa;   // row cy0+2 is only used when it exists
+        const uint32_t sh = (uint32_t)(cx0 & 3);
+        // all loads of the thread's frames first, then the arithmetic
+#pragma unroll 1
+        for (int k0 = 0; k0 < nf; k0 += RM_FR) {
+            Row12 r0[RM_FR], r1[RM_FR], r2[RM_FR];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                __builtin_memcpy(&lo[k][j], S + off[j], 2);
-                __builtin_memcpy(&hi[k][j], S + off[j] + (uint32_t)row_stride, 2);
+            for (int k = 0; k < RM_FR; k++) {
+                if (k0 + k < nf) {
+                    const uint8_t* S = src + (size_t)(f0 + k0 + k) * frame_stride;
+                    r0[k] = *reinterpret_cast<const Row12*>(S + o0);
+                    r1[k] = *reinterpret_cast<const Row12*>(S + o0 + (uint32_t)row_stride);
+                    r2[k] = *reinterpret_cast<const Row12*>(S + o2);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < RM_FR; k++) {
+                if (k0 + k < nf) {
+                    uint32_t out = 0;
+                    // byte 0 = column cx0
+                    const uint32_t a0 = __builtin_amdgcn_alignbyte(r0[k].b, r0[k].a, sh), a1 = __builtin_amdgcn_alignbyte(r0[k].c, r0[k].b, sh);
+                    const uint32_t b0 = __builtin_amdgcn_alignbyte(r1[k].b, r1[k].a, sh), b1 = __builtin_amdgcn_alignbyte(r1[k].c, r1[k].b, sh);
+                    const uint32_t c0 = __builtin_amdgcn_alignbyte(r2[k].b, r2[k].a, sh), c1 = __builtin_amdgcn_alignbyte(r2[k].c, r2[k].b, sh);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t a = __builtin_amdgcn_perm(a1, a0, sel[j]);
+                        const uint32_t b = __builtin_amdgcn_perm(b1, b0, sel[j]);
+                        const uint32_t c = __builtin_amdgcn_perm(c1, c0, sel[j]);
+                        uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(v2us_t, a), __builtin_bit_cast(v2us_t, w0[j]), 1u << 14, false);
+                        v = __builtin_amdgcn_udot2(__builtin_bit_cast(v2us_t, b), __builtin_bit_cast(v2us_t, w1[j]), v, false);
+                        v = __builtin_amdgcn_udot2(__builtin_bit_cast(v2us_t, c), __builtin_bit_cast(v2us_t, w2[j]), v, false);
+                        out |= (v >> 15) << (8 * j);
+                    }
+                    uint8_t* D = pyr + g.pyr_off + (size_t)(f0 + k0 + k) * g.plane_bytes;
+                    *reinterpret_cast<uint32_t*>(D + (size_t)r * g.pitch + 4 * c4) = out;
+                }
             }
         }
+        return;
     }
+#pragma unroll 1
+    for (int k0 = 0; k0 < nf; k0 += RM_FR) {
+        uint16_t lo[RM_FR][4], hi[RM_FR][4];
 #pragma unroll
-    for (int k = 0; k < RM_FR; k++) {
-        if (k < nf) {
-            uint32_t out = 0;
+        for (int k = 0; k < RM_FR; k++) {
+            if (k0 + k < nf) {
+                const uint8_t* S = src + (size_t)(f0 + k0 + k) * frame_stride;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t a = __builtin_amdgcn_perm(0, lo[k][j], 0x0C010C00u);   // byte0 | byte1 << 16
-                const uint32_t b = __builtin_amdgcn_perm(0, hi[k][j], 0x0C010C00u);
-                const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(v2us_t, a), __builtin_bit_cast(v2us_t, wa[j]),
-                                   __builtin_amdgcn_udot2(__builtin_bit_cast(v2us_t, b), __builtin_bit_cast(v2us_t, wb[j]), 1u << 14, false), false) >> 15;
-                out |= v << (8 * j);
+                for (int j = 0; j < 4; j++) {
+                    __builtin_memcpy(&lo[k][j], S + off[j], 2);
+                    __builtin_memcpy(&hi[k][j], S + off[j] + (uint32_t)row_stride, 2);
+                }
             }
-            uint8_t* D = pyr + g.pyr_off + (size_t)(f0 + k) * g.plane_bytes;
-            *reinterpret_cast<uint32_t*>(D + (size_t)r * g.pitch + 4 * c4) = out;
+        }
+#pragma unroll
+        for (int k = 0; k < RM_FR; k++) {
+            if (k0 + k < nf) {
+                uint32_t out = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t a = __builtin_amdgcn_perm(0, lo[k][j], 0x0C010C00u);   // byte0 | byte1 << 16
+                    const uint32_t b = __builtin_amdgcn_perm(0, hi[k][j], 0x0C010C00u);
+                    const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(v2us_t, a), __builtin_bit_cast(v2us_t, wa[j]),
+                                       __builtin_amdgcn_udot2(__builtin_bit_cast(v2us_t, b), __builtin_bit_cast(v2us_t, wb[j]), 1u << 14, false), false) >> 15;
+                    out |= v << (8 * j);
+                }
+                uint8_t* D = pyr + g.pyr_off + (size_t)(f0 + k0 + k) * g.plane_bytes;
+                *reinterpret_cast<uint32_t*>(D + (size_t)r * g.pitch + 4 * c4) = out;
+            }
         }
     }
 }
@@ -223,7 +290,6 @@ __global__ __launch_bounds__(256) void k_level0_remap(const uint8_t* __restrict_
 // ------------------------------------------------------------------------------------------------
 #define RS_RPT 8
 
-struct __attribute__((packed, aligned(4))) Row12 { uint32_t a, b, c; };
 typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 
 // src / dst: plane of frame 0 of the source / destination level (different levels never overlap,

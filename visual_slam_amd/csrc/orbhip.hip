@@ -363,7 +363,8 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
         if (e->d_map_x) {                                      // gray input through the rectification maps
             const int ndw = n16 * 4;
             hipLaunchKernelGGL(k_level0_remap, dim3((ndw + 63) / 64, (g.rows + 3) / 4, (frames + RM_FR - 1) / RM_FR), blk2, 0, s,
-                               d_imgs, row_stride, frame_stride, frames, e->d_map_x, e->d_map_y, W.d_pyr, g, ndw);
+                               d_imgs, row_stride, frame_stride, frames, e->d_map_x, e->d_map_y, W.d_pyr, g, ndw,
+                               (int)(((uintptr_t)d_imgs % 4 == 0) && (row_stride % 4 == 0) && (frame_stride % 4 == 0)));
         } else if (channels != 1) {
             const dim3 grid((g.rows * n16 + 255) / 256, frames);
             if (channels == 3)
