@@ -105,6 +105,19 @@ def profiled_traffic(kernel, frames):
         return None, None
 
 
+def profiled_valu(kernel, frames):
+    """Vector-ALU wave instructions per launch of `kernel` from the newest committed SQ counter
+    summary (profiles/*_valu.json, tools/pmc_valu.py), scaled to `frames` per launch."""
+    files = sorted((ROOT / "profiles").glob("*_valu.json"))
+    if not files:
+        return None, None
+    try:
+        t = json.loads(files[-1].read_text())
+        return int(t["kernels"][kernel]["valu_insts_per_launch"] * frames / t["frames_per_launch"]), files[-1].name
+    except (KeyError, ValueError):
+        return None, None
+
+
 def make_batch_on_device(torch, kind, w, h, nframes, device, nbase=16):
     """nbase host-generated frames, expanded on the device by distinct circular shifts."""
     from visual_slam_amd import synth
@@ -265,6 +278,13 @@ def main():
                     "whole_path_frac_of_copy": round(fps / world * total_bytes / 1e9 / copy_gbs, 4),
                     "frames_per_pass": int(frames_per_launch), "passes_in_flight": lanes,
                     "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in timing.items()}}
+        # the limit that actually binds the dominant kernel: vector-ALU issue. A wave64 instruction
+        # holds one of the 1024 SIMDs for 4 cycles; the rate below is at the 2.4 GHz peak clock.
+        valu, valu_src = profiled_valu(kname, frames_per_launch)
+        if valu:
+            peak_rate = 256 * 4 / 4.0 * 2.4e9
+            roofline["valu"] = {"wave_insts_per_launch": valu, "source": valu_src, "achieved_insts_per_s": round(valu / k_avg_s, 1),
+                                "peak_insts_per_s": peak_rate, "frac": round(valu / k_avg_s / peak_rate, 4)}
         # with several passes in flight (ORBHIP_LANES > 1) also time the same kernels one at a time (a
         # second handle limited to one pass, two untimed steps): a kernel with the GPU to itself
         if lanes > 1:
