@@ -1013,6 +1013,7 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     sincos_rounded(ang_rad, &a, &b);
     const int wv4 = g.w & ~3;
     const int ties_even = plan->blur_ties_even;
+    const uint16_t* hp_top = hp + 19 * DS_HP_P + 19;          // row sums of (row offset -3, column offset 0) from the keypoint
     unsigned long long bits[4];
 #pragma unroll
     for (int rnd = 0; rnd < 4; rnd++) {
@@ -1025,15 +1026,16 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
             const float py = (float)(signed char)(pk >> (16 * e + 8));
             const int ry = (int)rintf(px * b + py * a);
             const int rx = (int)rintf(px * a - py * b);
-            // taps < 2^6, row sums < 2^17: full-rate 24-bit multiplies are exact
-            const uint16_t* h = &hp[__mul24(ry + 22, DS_HP_P) + rx + 19];
-            const int acc = __mul24(t0, h[0]) + __mul24(t1, h[-DS_HP_P] + h[DS_HP_P]) +
-                            __mul24(t2, h[-2 * DS_HP_P] + h[2 * DS_HP_P]) + __mul24(t3, h[-3 * DS_HP_P] + h[3 * DS_HP_P]);
-            int qv = acc >> 16;
-            const int rem = acc & 0xFFFF;
-            if (rem > 32768) qv++;
-            else if (rem == 32768) qv += (ties_even && (kx + rx) < wv4) ? (qv & 1) : 1;
-            val[e] = qv > 255 ? 255 : qv;
+            // taps < 2^6, row sums < 2^17: full-rate 24-bit multiplies are exact. h = the top tap (row
+            // ry - 3), so that all seven reads have non-negative constant offsets.
+            const uint16_t* h = hp_top + (__mul24(ry, DS_HP_P) + rx);
+            const int acc = __mul24(t0, h[3 * DS_HP_P]) + __mul24(t1, h[2 * DS_HP_P] + h[4 * DS_HP_P]) +
+                            __mul24(t2, h[DS_HP_P] + h[5 * DS_HP_P]) + __mul24(t3, h[0] + h[6 * DS_HP_P]);
+            // round half up; the legacy column kernel rounds an exact half to even for x < (w & ~3)
+            uint32_t qv = (uint32_t)(acc + 0x8000) >> 16;
+            const bool tie_even = (acc & 0xFFFF) == 0x8000 && ties_even && (kx + rx) < wv4;
+            qv = tie_even ? (qv & ~1u) : qv;
+            val[e] = (int)min(qv, 255u);
         }
         bits[rnd] = __ballot(val[0] < val[1]);
     }
