@@ -69,10 +69,11 @@ struct PlanDev {
     // Byte weights of the orientation disc, one row of 32 bytes per |v| (byte i <-> u = i - 15):
     // words 0..7 hold 1 where |u| <= umax[|v|], words 8..15 hold u + 15 there; 0 elsewhere.
     uint32_t disc_w[16][16];
-    // Work items of the descriptor kernel's horizontal blur pass: row << 8 | first column (4 sums per
-    // item) of the 45 x 40 grid of row sums, only where a rotated test point can ever need them
-    // (the pattern lies inside a circle of radius sqrt(338)); padded with repeats to ORB_HP_ITEMS.
-    uint16_t hp_items[ORB_HP_ITEMS];
+    // Work items of the descriptor kernel's horizontal blur pass (4 adjacent sums of one row of the
+    // 45 x 40 grid of row sums per item), only where a rotated test point can ever need them (the
+    // pattern lies inside a circle of radius sqrt(338)): byte offset of the item's first pixel in the
+    // staged patch | byte offset of its first sum << 16; padded with repeats to ORB_HP_ITEMS.
+    uint32_t hp_items[ORB_HP_ITEMS];
     // k_fast handles all levels in one launch: workgroups [fast_cum[l] * frames, fast_cum[l+1] * frames)
     // belong to level l (fast_cum = running sum of tiles per frame); magics for the divisions by the
     // tiles per frame and the tiles per row of a level (grid_magic)

@@ -834,6 +834,8 @@ __device__ __align__(16) const signed char d_pattern[1024] = {
 #include "../../include/orb_pattern_31.inc"
 };
 
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {   // cv::fastAtan2
     const float s = (float)(180 / 3.141592653589793238462643383279502884);
     const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s;
@@ -992,8 +994,8 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     for (int k = 0; k < ORB_HP_ITEMS / 64; k++) items[k] = plan->hp_items[64 * k + lane];
 #pragma unroll
     for (int k = 0; k < ORB_HP_ITEMS / 64; k++) {
-        const int r = (int)(items[k] >> 8), c = (int)(items[k] & 0xFF);   // sums c..c+3 of row r (column 39 is padding)
-        const uint32_t* rw = reinterpret_cast<const uint32_t*>(&raw[r * DS_RAW_P + c]);
+        // sums c..c+3 of row r (column 39 is padding): the item holds both byte offsets
+        const uint32_t* rw = reinterpret_cast<const uint32_t*>(raw + (items[k] & 0xFFFF));
         const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2], d3 = rw[3];
         const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, off), e1 = __builtin_amdgcn_alignbyte(d2, d1, off),
                        e2 = __builtin_amdgcn_alignbyte(d3, d2, off);          // bytes off+c .. off+c+11
@@ -1004,7 +1006,7 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
             const uint32_t hi = q ? __builtin_amdgcn_alignbyte(e2, e1, q) : e1;   // taps at c+q+4 .. c+q+6
             acc[q] = __builtin_amdgcn_udot4(lo, tap_lo, __builtin_amdgcn_udot4(hi, tap_hi, 0u, false), false);
         }
-        *reinterpret_cast<uint2*>(&hp[r * DS_HP_P + c]) = make_uint2(acc[0] | (acc[1] << 16), acc[2] | (acc[3] << 16));
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(hp) + (items[k] >> 16)) = make_uint2(acc[0] | (acc[1] << 16), acc[2] | (acc[3] << 16));
     }
     // ---- steered BRIEF (src/ORBextractor.cc:107-147)
     const float factorPI = (float)(3.141592653589793238462643383279502884 / 180.f);
@@ -1013,6 +1015,7 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     sincos_rounded(ang_rad, &a, &b);
     const int wv4 = g.w & ~3;
     const int ties_even = plan->blur_ties_even;
+    const v2f_t ab = {a, b}, ba = {b, a};
     const uint16_t* hp_top = hp + 19 * DS_HP_P + 19;          // row sums of (row offset -3, column offset 0) from the keypoint
     unsigned long long bits[4];
 #pragma unroll
@@ -1024,8 +1027,11 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
         for (int e = 0; e < 2; e++) {
             const float px = (float)(signed char)(pk >> (16 * e));
             const float py = (float)(signed char)(pk >> (16 * e + 8));
-            const int ry = (int)rintf(px * b + py * a);
-            const int rx = (int)rintf(px * a - py * b);
+            // (rx, ry) = round(px * a - py * b, px * b + py * a): two packed multiplies, each product
+            // rounded on its own as in the scalar expression
+            const v2f_t pxv = v2f_t{px, px} * ab, pyv = v2f_t{py, py} * ba;
+            const int rx = (int)rintf(pxv.x - pyv.x);
+            const int ry = (int)rintf(pxv.y + pyv.y);
             // taps < 2^6, row sums < 2^17: full-rate 24-bit multiplies are exact. h = the top tap (row
             // ry - 3), so that all seven reads have non-negative constant offsets.
             const uint16_t* h = hp_top + (__mul24(ry, DS_HP_P) + rx);

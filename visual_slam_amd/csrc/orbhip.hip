@@ -209,7 +209,7 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
             if (t < 0 || dy + 22 < 0 || dy + 22 > 44) continue;
             const int m = std::min((int)std::floor(0.5 + std::sqrt(t)), 19);
             for (int g = (19 - m) >> 2; g <= std::min((19 + m) >> 2, 9); g++)
-                if (n < ORB_HP_ITEMS) P.hp_items[n++] = (uint16_t)(((dy + 22) << 8) | (4 * g));
+                if (n < ORB_HP_ITEMS) P.hp_items[n++] = (uint32_t)((dy + 22) * DS_RAW_P + 4 * g) | ((uint32_t)(((dy + 22) * DS_HP_P + 4 * g) * 2) << 16);
                 else { e->err = "internal: blur work list overflow"; return ORBHIP_ERR_ARG; }
         }
         for (int i = n; i < ORB_HP_ITEMS; i++) P.hp_items[i] = P.hp_items[i - n];   // repeats write the same values again
