@@ -35,6 +35,7 @@ struct LevelGeom {
     int maxbx, maxby;         // maxBorderX/Y = w-16, h-16
     int ncols, nrows, wcell, hcell;
     unsigned wcell_magic, hcell_magic;   // floor(2^32/d)+1: n/d == umulhi(n, magic) for n < 65536, 1 < d < 65536
+    unsigned wcell_m22, hcell_m22;       // ceil(2^22/d): n/d == (n * m) >> 22 for n * d < 2^22, a 24-bit multiply
     // FAST output segments
     int ntx, nty;             // tiles of k_fast in x and y; 4 segments per tile
     unsigned long long seg_off;      // entry offset of this level's first segment inside a frame's segment block

@@ -190,7 +190,7 @@ __device__ __forceinline__ void fast_score_queue(const uint16_t* queue, int n, i
         const uint32_t e = queue[lane];
         const int xl = (int)((e >> 3) & 0xFC) + (int)((e >> 3) & 3);        // 4 * lane + pixel
         const int row = m0 + FT_GROUP * (int)(e >> 11) + (int)(~e & 7);
-        const uint8_t* c = img + (row + 3) * FT_P + xl;
+        const uint8_t* c = img + (__mul24(row, FT_P) + 3 * FT_P + xl);   // 24-bit multiplies run at full rate
         int p[16];
         p[0] = c[3 * FT_P];      p[1] = c[3 * FT_P + 1];   p[2] = c[2 * FT_P + 2];   p[3] = c[FT_P + 3];
         p[4] = c[3];             p[5] = c[-FT_P + 3];      p[6] = c[-2 * FT_P + 2];  p[7] = c[-3 * FT_P + 1];
@@ -198,7 +198,7 @@ __device__ __forceinline__ void fast_score_queue(const uint16_t* queue, int n, i
         p[12] = c[-3];           p[13] = c[FT_P - 3];      p[14] = c[2 * FT_P - 2];  p[15] = c[3 * FT_P - 1];
         const int s = fast_score16(c[0], p);
         if (s >= min_th) {
-            map[row * FT_P + xl] = (uint8_t)s;
+            map[__mul24(row, FT_P) + xl] = (uint8_t)s;
             hit = fast_is_output(row, xl);
             code = (uint32_t)(row << 8 | xl);
         }
@@ -214,8 +214,9 @@ __device__ __forceinline__ void fast_score_queue2(const uint16_t* queue, int n, 
     const uint32_t ea = queue[lane], eb = queue[two ? lane + 64 : lane];
     const int xa = (int)((ea >> 3) & 0xFC) + (int)((ea >> 3) & 3), xb = (int)((eb >> 3) & 0xFC) + (int)((eb >> 3) & 3);
     const int ra = m0 + FT_GROUP * (int)(ea >> 11) + (int)(~ea & 7), rb = m0 + FT_GROUP * (int)(eb >> 11) + (int)(~eb & 7);
-    const uint8_t* ca = img + (ra + 3) * FT_P + xa;
-    const uint8_t* cb = img + (rb + 3) * FT_P + xb;
+    const int pa = __mul24(ra, FT_P) + xa, pb = __mul24(rb, FT_P) + xb;   // 24-bit multiplies run at full rate
+    const uint8_t* ca = img + (pa + 3 * FT_P);
+    const uint8_t* cb = img + (pb + 3 * FT_P);
     constexpr int ring[16] = {3 * FT_P, 3 * FT_P + 1, 2 * FT_P + 2, FT_P + 3, 3, -FT_P + 3, -2 * FT_P + 2, -3 * FT_P + 1,
                               -3 * FT_P, -3 * FT_P - 1, -2 * FT_P - 2, -FT_P - 3, -3, FT_P - 3, 2 * FT_P - 2, 3 * FT_P - 1};
     v2s p[16];
@@ -224,8 +225,8 @@ __device__ __forceinline__ void fast_score_queue2(const uint16_t* queue, int n, 
     const v2s v = {(short)ca[0], (short)cb[0]};
     const v2s s = fast_score16_pk(v, p);
     const bool sa = s.x >= min_th, sb = two && s.y >= min_th;
-    if (sa) map[ra * FT_P + xa] = (uint8_t)s.x;
-    if (sb) map[rb * FT_P + xb] = (uint8_t)s.y;
+    if (sa) map[pa] = (uint8_t)s.x;
+    if (sb) map[pb] = (uint8_t)s.y;
     fast_list_append(sa && fast_is_output(ra, xa), (uint32_t)(ra << 8 | xa), sb && fast_is_output(rb, xb), (uint32_t)(rb << 8 | xb),
                      lane, list, nlist);
 }
@@ -406,12 +407,13 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
         bool keep = false;
         int x = 0, y = 0, s = 0;
         if (have) {
-            const uint8_t* c = &s_map[m * FT_P + xl];
+            const uint8_t* c = &s_map[__mul24(m, FT_P) + xl];
             s = c[0];
             x = xs - 4 + xl; y = y0 - 1 + m;
             const int ux = x - ORB_EDGE, uy = y - ORB_EDGE;
-            const int xin = ux - __mul24((int)__umulhi((uint32_t)ux, g.wcell_magic), g.wcell);
-            const int yin = uy - __mul24((int)__umulhi((uint32_t)uy, g.hcell_magic), g.hcell);
+            // position inside the cell: n / d == n * ceil(2^22 / d) >> 22 for n * d < 2^22 (full-rate multiplies)
+            const int xin = ux - __mul24((int)(__umul24((uint32_t)ux, g.wcell_m22) >> 22), g.wcell);
+            const int yin = uy - __mul24((int)(__umul24((uint32_t)uy, g.hcell_m22) >> 22), g.hcell);
             const bool l = xin > 0, r = xin < g.wcell - 1, u = yin > 0, d = yin < g.hcell - 1;
             // all eight reads are in range (the map has a one-pixel halo); issue them together
             const int nw_ = c[-FT_P - 1], n_ = c[-FT_P], ne_ = c[-FT_P + 1], w_ = c[-1], e_ = c[1];

@@ -548,8 +548,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
                 keys[p] = e[u];
                 if ((int)(e[u].y & 0xFF) >= ini_th) {
                     const int x = e[u].x & 0xFFFF, y = e[u].x >> 16;
-                    const int c = (int)__umulhi((uint32_t)(y - 3), g.hcell_magic) * g.ncols +
-                                  (int)__umulhi((uint32_t)(x - 3), g.wcell_magic);
+                    const int c = __mul24((int)(__umul24((uint32_t)(y - 3), g.hcell_m22) >> 22), g.ncols) +
+                                  (int)(__umul24((uint32_t)(x - 3), g.wcell_m22) >> 22);
                     atomicOr(&cellbits[c >> 5], 1u << (c & 31));
                 }
             }
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
 #pragma unroll
         for (int u = 0; u < QT_KU; u++) {
             x[u] = e[u].x & 0xFFFF; y[u] = e[u].x >> 16; s[u] = e[u].y & 0xFF;
-            cell[u] = (int)__umulhi((uint32_t)(y[u] - 3), g.hcell_magic) * g.ncols + (int)__umulhi((uint32_t)(x[u] - 3), g.wcell_magic);
+            cell[u] = __mul24((int)(__umul24((uint32_t)(y[u] - 3), g.hcell_m22) >> 22), g.ncols) + (int)(__umul24((uint32_t)(x[u] - 3), g.wcell_m22) >> 22);
             cb[u] = cellbits[cell[u] >> 5];
             root[u] = min(max((int)__fdiv_rn((float)x[u], g.hx), 0), L - 1);
             b0[u] = q.box[0][2 * root[u]]; b1[u] = q.box[0][2 * root[u] + 1];
@@ -786,10 +786,12 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
                 for (int u = 0; u < QT_KU; u++) {
                     if (!alive[u]) continue;
                     const int x = e[u].x & 0xFFFF, y = e[u].x >> 16;
-                    const int cx = (int)__umulhi((uint32_t)(x - 3), g.wcell_magic);
-                    const int cy = (int)__umulhi((uint32_t)(y - 3), g.hcell_magic);
-                    const uint32_t ord = (uint32_t)(((cy * g.ncols + cx) * g.hcell + (y - 3 - cy * g.hcell)) * g.wcell +
-                                                    (x - 3 - cx * g.wcell));
+                    const int cx = (int)(__umul24((uint32_t)(x - 3), g.wcell_m22) >> 22);
+                    const int cy = (int)(__umul24((uint32_t)(y - 3), g.hcell_m22) >> 22);
+                    // (every factor stays below 2^24 and every product below 2^32: full-rate 24-bit multiplies)
+                    const uint32_t row_in_cells = __umul24((uint32_t)(__mul24(cy, g.ncols) + cx), (uint32_t)g.hcell) +
+                                                  (uint32_t)(y - 3 - __mul24(cy, g.hcell));
+                    const uint32_t ord = __umul24(row_in_cells, (uint32_t)g.wcell) + (uint32_t)(x - 3 - __mul24(cx, g.wcell));
                     atomicMax(&q.key64[nl[u]], ((unsigned long long)(e[u].y & 0xFF) << 32) | (0xFFFFFFFFu - ord));
                 }
             });
