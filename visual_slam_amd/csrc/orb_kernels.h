@@ -395,7 +395,9 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 // column, raster), encoded as `ord`. Equal-size nodes in the final expansion rounds are taken in
 // reverse creation order (the reference compares heap addresses there).
 // ------------------------------------------------------------------------------------------------
+#ifndef QT_THREADS
 #define QT_THREADS 256
+#endif
 #define QT_FRESH 0x80000000u
 
 struct QtShared {
