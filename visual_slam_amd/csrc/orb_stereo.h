@@ -165,16 +165,21 @@ __global__ __launch_bounds__(256) void k_stereo_match(const PlanDev* __restrict_
             const int yl0 = (int)(scaledvL - w), xl0 = (int)(scaleduL - w), xr00 = (int)(scaleduR0 - L - w);
             int* dist = s_dist[wv];
             if (lane < 11) dist[lane] = 0;
-            const int cL = PL[(yl0 + w) * g.pitch + xl0 + w];
+            // (24-bit multiplies run at full rate; a plane is far below 2^24 rows x 2^24 bytes of pitch)
+            const int cL = PL[__mul24(yl0 + w, g.pitch) + xl0 + w];
             for (int t = lane; t < 121; t += 64) {
-                const int i = t / 11, k = t - i * 11;           // patch row, offset index (incR = k - 5)
-                const uint8_t* rl = PL + (yl0 + i) * g.pitch + xl0;
-                const uint8_t* rr = PR + (yl0 + i) * g.pitch + xr00 + k;
-                const int cR = PR[(yl0 + w) * g.pitch + xr00 + k + w];
-                int acc = 0;
+                const int i = __mul24(t, 745) >> 13, k = t - i * 11;   // t / 11 for t < 121: patch row, offset index (incR = k - 5)
+                const int rowoff = __mul24(yl0 + i, g.pitch);
+                const uint8_t* rl = PL + (rowoff + xl0);
+                const uint8_t* rr = PR + (rowoff + xr00 + k);
+                const int cR = PR[__mul24(yl0 + w, g.pitch) + xr00 + k + w];
+                // |(l - cL) - (r - cR)| = |(l + da) - (r + db)| with da = max(cR - cL, 0), db = max(cL - cR, 0):
+                // both sides stay non-negative, so the unsigned sum-of-absolute-differences instruction applies
+                const uint32_t da = (uint32_t)max(cR - cL, 0), db = (uint32_t)max(cL - cR, 0);
+                uint32_t acc = 0;
 #pragma unroll
-                for (int j = 0; j < 11; j++) acc += abs(((int)rl[j] - cL) - ((int)rr[j] - cR));
-                atomicAdd(&dist[k], acc);
+                for (int j = 0; j < 11; j++) acc = __usad((uint32_t)rl[j] + da, (uint32_t)rr[j] + db, acc);
+                atomicAdd(&dist[k], (int)acc);
             }
             // LDS operations of one wave complete in order: the sums are final when read back
             const int dk = lane < 11 ? dist[lane] : 0x7FFFFF;
