@@ -83,6 +83,11 @@ struct orbhip_extractor {
     size_t qt_lds = 0;
     int last_pass_frames = 0;
     int last_ws = 0;               // workspace of the last pass (pyramid / candidate read-back)
+    unsigned long long pass_gen = 0;       // counts passes: tags the host copy of a frame's pyramid
+    uint8_t* h_pyr = nullptr;      // pinned host copy of all levels of one frame (orbhip_pyramid_copy)
+    size_t h_pyr_bytes = 0;
+    unsigned long long h_pyr_gen = 0;
+    int h_pyr_frame = -1;
     // staging for the host entry points
     uint8_t* d_in = nullptr; size_t d_in_bytes = 0;
     uint8_t* h_in = nullptr; size_t h_in_bytes = 0;      // pinned: rows are packed here, then one copy up
@@ -435,6 +440,7 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
     HIP_TRY(e, hipGetLastError());
     e->last_pass_frames = frames;
     e->last_ws = (int)(&W - e->ws);
+    e->pass_gen++;
     return ORBHIP_OK;
 }
 
@@ -542,6 +548,7 @@ int orbhip_destroy(orbhip_extractor* e) {
     dfree(e->d_map_x); dfree(e->d_map_y);
     if (e->h_in) (void)hipHostFree(e->h_in);
     if (e->h_out) (void)hipHostFree(e->h_out);
+    if (e->h_pyr) (void)hipHostFree(e->h_pyr);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     for (Workspace& w : e->ws) {
         if (w.stream) (void)hipStreamDestroy(w.stream);
@@ -769,21 +776,35 @@ int orbhip_pyramid_copy(orbhip_extractor* e, int frame, int level, uint8_t* dst,
     const int b = with_border ? ORB_EDGE : 0;
     if (dst_stride < (size_t)(g.w + 2 * b)) return ORBHIP_ERR_ARG;
     HIP_TRY(e, hipSetDevice(e->device));
-    HIP_TRY(e, hipDeviceSynchronize());
-    // the rows of the plane are contiguous in device memory: one copy into pinned memory, then the
-    // rows are cut out on the host (a 2-D copy into pageable memory would go row by row)
-    const int rows = g.h + 2 * b;
-    const size_t bytes = (size_t)rows * g.pitch;
-    if (bytes > e->h_out_bytes) {
-        if (e->h_out) (void)hipHostFree(e->h_out);
-        e->h_out = nullptr; e->h_out_bytes = 0;
-        HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_out), bytes, hipHostMallocDefault));
-        e->h_out_bytes = bytes;
+    // The first request for a frame after a pass brings all levels of that frame into pinned host
+    // memory (one asynchronous copy per level, one wait: callers such as the C++ class ask for every
+    // level in turn); the rows are then cut out on the host (a 2-D copy into pageable memory would
+    // go row by row).
+    if (e->h_pyr_gen != e->pass_gen || e->h_pyr_frame != frame) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        if (e->pyr_bytes_per_frame > e->h_pyr_bytes) {
+            if (e->h_pyr) (void)hipHostFree(e->h_pyr);
+            e->h_pyr = nullptr; e->h_pyr_bytes = 0;
+            HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_pyr), e->pyr_bytes_per_frame, hipHostMallocDefault));
+            e->h_pyr_bytes = e->pyr_bytes_per_frame;
+        }
+        size_t off = 0;
+        for (int l = 0; l < e->prm.nlevels; l++) {
+            const LevelGeom& gl = e->plan.lv[l];
+            HIP_TRY(e, hipMemcpyAsync(e->h_pyr + off, e->ws[e->last_ws].d_pyr + gl.pyr_off + (size_t)frame * gl.plane_bytes,
+                                      gl.plane_bytes, hipMemcpyDeviceToHost, e->stream));
+            off += gl.plane_bytes;
+        }
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        e->h_pyr_gen = e->pass_gen;
+        e->h_pyr_frame = frame;
     }
-    const uint8_t* src = e->ws[e->last_ws].d_pyr + g.pyr_off + (size_t)frame * g.plane_bytes + (size_t)(ORB_OY - b) * g.pitch;
-    HIP_TRY(e, hipMemcpy(e->h_out, src, bytes, hipMemcpyDeviceToHost));
+    size_t off = 0;
+    for (int l = 0; l < level; l++) off += e->plan.lv[l].plane_bytes;
+    const int rows = g.h + 2 * b;
+    const uint8_t* src = e->h_pyr + off + (size_t)(ORB_OY - b) * g.pitch + (ORB_OX - b);
     for (int y = 0; y < rows; y++)
-        std::memcpy(dst + (size_t)y * dst_stride, e->h_out + (size_t)y * g.pitch + (ORB_OX - b), (size_t)(g.w + 2 * b));
+        std::memcpy(dst + (size_t)y * dst_stride, src + (size_t)y * g.pitch, (size_t)(g.w + 2 * b));
     return ORBHIP_OK;
 }
 
