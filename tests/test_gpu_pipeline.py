@@ -1,0 +1,121 @@
+"""The device entry points chained as a stereo tracking front-end would chain them, on one stream
+and without a host round trip in between: rectification + extraction of both eyes at two time steps,
+stereo matching (reference src/Frame.cc:481-653), undistortion (src/Frame.cc:422-449) and the
+motion-model matcher (src/ORBmatcher.cc:1324-1445) between the two steps. Every stage is compared
+with the oracle run stage by stage on the host: besides the arithmetic this checks the ordering of
+the calls against each other (streams, workspaces that later passes overwrite)."""
+import numpy as np
+import pytest
+
+from visual_slam_amd import synth
+
+KITTI = (718.856, 718.856, 607.1928, 185.2157, 0.0, 0.0, 0.0, 0.0, 0.0)
+Z = 0.54 * 718.856 / 14.0          # depth that a 14-px disparity means for this rig
+
+
+def shifted(img, dx, dy):
+    out = img.copy()
+    h, w = img.shape
+    out[max(dy, 0):h + min(dy, 0), max(dx, 0):w + min(dx, 0)] = img[max(-dy, 0):h + min(-dy, 0), max(-dx, 0):w + min(-dx, 0)]
+    return out
+
+
+@pytest.mark.gpu
+def test_stereo_front_end_chain_matches_oracle_stage_by_stage():
+    import torch
+    from oracle import orb_oracle as O
+    from visual_slam_amd import orbhip
+    n, w, h, prm = 3, 640, 360, (800, 1.2, 8, 20, 7)
+    fx, fy, cx, cy = KITTI[:4]
+    bf = 0.54 * fx
+    mb = bf / fx
+    motion = [(6, -3), (-9, 2), (3, 5)]
+    mx, my = synth.rectify_maps(w, h, 0.8, 0.04, (1.3, -0.7))
+    # raw images: time 0 and time 1 (image motion) of the left eye; the right eye sees the content moved by the disparity
+    L0 = np.stack([synth.frame("blocks", w, h, 300 + i) for i in range(n)])
+    L1 = np.stack([shifted(L0[i], *motion[i]) for i in range(n)])
+    R0 = np.stack([shifted(L0[i], -14, 0) for i in range(n)])
+    R1 = np.stack([shifted(L1[i], -14, 0) for i in range(n)])
+    bounds = orbhip.ComputeImageBounds(KITTI, w, h)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    sp = stream.cuda_stream
+    gL, gR = orbhip.ORBextractor(*prm), orbhip.ORBextractor(*prm)
+    gL.set_rectification(mx, my); gR.set_rectification(mx, my)
+    cap = gL.max_keypoints()
+    lib = orbhip.lib()
+    cam_c = orbhip._cam(np.array(KITTI, np.float32)); b_c = np.ascontiguousarray(bounds, np.float32)
+
+    def outputs():
+        return (torch.zeros((n, cap, 7), dtype=torch.float32, device=dev), torch.zeros((n, cap, 32), dtype=torch.uint8, device=dev),
+                torch.zeros((n,), dtype=torch.int32, device=dev))
+
+    with torch.cuda.stream(stream):
+        dimg = {k: torch.from_numpy(v).to(dev) for k, v in (("L0", L0), ("R0", R0), ("L1", L1), ("R1", R1))}
+        res = {k: outputs() for k in dimg}
+        un = {k: torch.zeros((n, cap, 7), dtype=torch.float32, device=dev) for k in ("L0", "L1")}
+        ur = {k: torch.zeros((n, cap), dtype=torch.float32, device=dev) for k in ("0", "1")}
+        dp = {k: torch.zeros((n, cap), dtype=torch.float32, device=dev) for k in ("0", "1")}
+        nm = {k: torch.zeros((n,), dtype=torch.int32, device=dev) for k in ("0", "1")}
+        gs = torch.zeros((n, orbhip.GRID_CELLS + 1), dtype=torch.int32, device=dev)
+        gi = torch.zeros((n, cap), dtype=torch.int32, device=dev)
+        match = torch.zeros((n, cap), dtype=torch.int32, device=dev)
+        nmatch = torch.zeros((n,), dtype=torch.int32, device=dev)
+    stream.synchronize()
+    # time step t: both eyes, stereo matching, undistortion of the left keypoints -- all enqueued, no waits
+    for t in ("0", "1"):
+        for eye, g in (("L", gL), ("R", gR)):
+            k, d, c = res[eye + t]
+            g.extract_batch_device(dimg[eye + t].data_ptr(), n, w, h, w, w * h, k.data_ptr(), d.data_ptr(), c.data_ptr(), cap, stream=sp)
+        (kl, dl, cl), (kr, dr, cr) = res["L" + t], res["R" + t]
+        orbhip.stereo_match_batch_device(gL, gR, n, kl.data_ptr(), dl.data_ptr(), cl.data_ptr(), kr.data_ptr(), dr.data_ptr(),
+                                         cr.data_ptr(), cap, mb, bf, ur[t].data_ptr(), dp[t].data_ptr(), nm[t].data_ptr(), stream=sp)
+        gL._check(lib.orbhip_undistort_grid_batch_device(gL._h, n, kl.data_ptr(), cl.data_ptr(), cap, orbhip._ptr(cam_c), orbhip._ptr(b_c),
+                                                         un["L" + t].data_ptr(), gs.data_ptr(), gi.data_ptr(), sp))
+    stream.synchronize()
+    # map points of step 0: left keypoints with a stereo depth, back-projected (the host's job in the reference)
+    hu0, hdp0, hc0 = un["L0"].cpu().numpy(), dp["0"].cpu().numpy(), res["L0"][2].cpu().numpy()
+    z = np.where(hdp0 > 0, hdp0, 1.0)
+    world = np.stack([(hu0[..., 0] - cx) * z / fx, (hu0[..., 1] - cy) * z / fy, z], axis=2).astype(np.float32)
+    flags = (hdp0 > 0).astype(np.uint8) * 3
+    Tcw = np.stack([np.concatenate([np.eye(3).ravel(), [dx * Z / fx, dy * Z / fy, 0.0]]) for dx, dy in motion]).astype(np.float32)
+    with torch.cuda.stream(stream):
+        dw, df, dT = (torch.from_numpy(a).to(dev) for a in (world, flags, Tcw))
+    stream.synchronize()
+    prm_p = orbhip.projection_params(KITTI[:4], bf, bounds, 7.0, True)
+    orbhip.search_by_projection_batch_device(gL, n, cap, un["L0"].data_ptr(), dw.data_ptr(), df.data_ptr(), res["L0"][1].data_ptr(),
+                                             res["L0"][2].data_ptr(), un["L1"].data_ptr(), res["L1"][1].data_ptr(), ur["1"].data_ptr(),
+                                             res["L1"][2].data_ptr(), dT.data_ptr(), None, prm_p, match.data_ptr(), nmatch.data_ptr(),
+                                             stream=sp)
+    stream.synchronize()
+
+    # ---- the same chain on the host, stage by stage
+    total_stereo = total_proj = 0
+    for i in range(n):
+        o = {}
+        for key, raw in (("L0", L0), ("R0", R0), ("L1", L1), ("R1", R1)):
+            ex = O.OracleExtractor(*prm)
+            kp, desc = ex.extract(O.remap_linear(raw[i], mx, my))
+            o[key] = (ex, kp, desc)
+            c = int(res[key][2][i].item())
+            assert c == len(kp), (i, key)
+            assert np.array_equal(res[key][1][i, :c].cpu().numpy(), desc), (i, key)
+        st = {}
+        for t in ("0", "1"):
+            (eL, kl, dl), (eR, kr, dr) = o["L" + t], o["R" + t]
+            ou, od, on = O.stereo_match(eL, eR, kl, dl, kr, dr, mb, bf)
+            c = len(kl)
+            assert int(nm[t][i].item()) == on
+            assert np.array_equal(ur[t][i, :c].cpu().numpy().view(np.uint32), ou.view(np.uint32)), (i, t)
+            assert np.array_equal(dp[t][i, :c].cpu().numpy().view(np.uint32), od.view(np.uint32)), (i, t)
+            st[t] = (ou, od)
+            total_stereo += on
+        u0 = O.undistort_grid(KITTI, bounds, o["L0"][1])[0]
+        u1 = O.undistort_grid(KITTI, bounds, o["L1"][1])[0]
+        c0, c1 = len(u0), len(u1)
+        om, on = O.search_by_projection(u0, world[i, :c0], flags[i, :c0], o["L0"][2], u1, o["L1"][2], st["1"][0], Tcw[i],
+                                        KITTI[:4], bf, bounds, o["L0"][0].table(0), 7.0, 0, True)
+        assert int(nmatch[i].item()) == on, i
+        assert np.array_equal(match[i, :c1].cpu().numpy(), om), i
+        total_proj += on
+    assert total_stereo > 6 * 100 and total_proj > 3 * 30
