@@ -451,3 +451,232 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_proj(const GridKp* __rest
         nmatches_out[f] = s_made - bad_all;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchForInitialization again (reference src/ORBmatcher.cc:402-517), organised like
+// k_search_proj: the loop over F1 is sequential only through vMatchedDistance (a candidate that an
+// earlier keypoint holds at a distance not larger is skipped). First every level-0 keypoint of F1
+// lists, in parallel and with that rule ignored, its best few candidates in the reference's order of
+// preference (distance, cell, index); candidates that can decide nothing are left out (distance
+// above TH_LOW and large enough that, as a second best, it lets every acceptable best through).
+// Then one wave walks F1 in order: the first two listed candidates that the rule does not skip are
+// the reference's best and second best; a list that ends too early is replaced by a search with the
+// rule applied. One workgroup (MP_THREADS / 64 waves) per frame pair; k_search_init above remains
+// for frames with more keypoints than this kernel's LDS state holds.
+// ------------------------------------------------------------------------------------------------
+#define MI_LDS_PER_KP 36      // dynamic LDS bytes per keypoint slot
+
+__global__ __launch_bounds__(MP_THREADS) void k_search_init_par(const GridKp* __restrict__ kp1, const uint8_t* __restrict__ desc1,
+                                                                const int* __restrict__ cnt1, const GridKp* __restrict__ kp2,
+                                                                const uint8_t* __restrict__ desc2, const int* __restrict__ cnt2,
+                                                                int cap, float min_x, float min_y, float inv_w, float inv_h,
+                                                                float window, float nnratio, int check_orientation,
+                                                                float2* __restrict__ prev_matched, int* __restrict__ matches12,
+                                                                int* __restrict__ nmatches_out) {
+    extern __shared__ __align__(16) uint8_t mi_smem[];
+    uint32_t* list1 = reinterpret_cast<uint32_t*>(mi_smem);                  // F1: MP_LIST x (distance << 16 | F2 index), best first
+    float2* pos2 = reinterpret_cast<float2*>(list1 + MP_LIST * (size_t)cap);  // F2: position
+    uint16_t* sorted2 = reinterpret_cast<uint16_t*>(pos2 + cap);             // F2 level-0 indices bucketed by grid cell
+    uint16_t* cell2 = sorted2 + cap;                                         // F2: grid cell, 0xFFFF = never a candidate
+    uint16_t* matched_dist = cell2 + cap;                                    // vMatchedDistance (0xFFFF = INT_MAX)
+    uint16_t* matches21 = matched_dist + cap;                                // vnMatches21 (0xFFFF = -1)
+    uint16_t* taken1 = matches21 + cap;                                      // F1: the F2 keypoint it was matched to (at that time)
+    uint8_t* bin1 = reinterpret_cast<uint8_t*>(taken1 + cap);                // F1: rotation bin of that match, 0xFE = pending, 0xFF = none
+    uint8_t* lvl0 = bin1 + cap;                                              // F1: 1 = octave 0 (the others are not matched, src/ORBmatcher.cc:418-420)
+    __shared__ uint32_t s_cur[GRID_CELLS];
+    __shared__ uint16_t s_start[GRID_CELLS + 2];
+    __shared__ uint32_t s_magic[GRID_ROWS + 1];
+    __shared__ uint32_t s_tmp[MP_WAVES];
+    __shared__ int s_hist[MT_HISTO];
+    const int tid = threadIdx.x, lane = tid & 63, f = blockIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t o = (size_t)f * cap;
+    const int n1 = min(cnt1[f], cap), n2 = min(cnt2[f], cap);
+    const GridKp* K1 = kp1 + o;
+    const GridKp* K2 = kp2 + o;
+    int* m12 = matches12 + o;
+    float2* prev = prev_matched + o;
+    const float r = window;
+
+    for (int c = tid; c < GRID_CELLS; c += MP_THREADS) s_cur[c] = 0;
+    if (tid >= 1 && tid <= GRID_ROWS) s_magic[tid] = ((1u << 20) + tid - 1) / tid;
+    if (tid < MT_HISTO) s_hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n2; i += MP_THREADS) {
+        const GridKp k = K2[i];
+        int cell = grid_cell(k.x, k.y, min_x, min_y, inv_w, inv_h);
+        if (k.octave != 0) cell = -1;                          // minLevel = maxLevel = 0 (src/ORBmatcher.cc:423)
+        pos2[i] = make_float2(k.x, k.y);
+        cell2[i] = (uint16_t)(cell < 0 ? 0xFFFF : cell);
+        matched_dist[i] = 0xFFFF;
+        matches21[i] = 0xFFFF;
+        if (cell >= 0) atomicAdd(&s_cur[cell], 1u);
+    }
+    for (int i = tid; i < n1; i += MP_THREADS) { bin1[i] = 0xFF; m12[i] = -1; list1[MP_LIST * i] = MP_END; lvl0[i] = K1[i].octave == 0; }
+    __syncthreads();
+    const uint32_t total = mp_block_excl_scan(s_cur, GRID_CELLS, s_tmp);
+    for (int c = tid; c < GRID_CELLS; c += MP_THREADS) s_start[c] = (uint16_t)s_cur[c];
+    if (tid == 0) s_start[GRID_CELLS] = (uint16_t)total;
+    __syncthreads();
+    for (int i = tid; i < n2; i += MP_THREADS) {
+        const int cell = cell2[i];
+        if (cell != 0xFFFF) sorted2[atomicAdd(&s_cur[cell], 1u)] = (uint16_t)i;
+    }
+    __syncthreads();
+
+    // Visits the candidates of F1 keypoint i1 (F2 level-0 keypoints inside the window around its
+    // vbPrevMatched entry, Frame::GetFeaturesInArea src/Frame.cc:351-401), lanes over the cells.
+    auto for_candidates = [&](int i1, auto&& body) __attribute__((always_inline)) {
+        const float2 p = prev[i1];
+        const int min_cx = max(0, (int)floorf((p.x - min_x - r) * inv_w));
+        const int max_cx = min(GRID_COLS - 1, (int)ceilf((p.x - min_x + r) * inv_w));
+        const int min_cy = max(0, (int)floorf((p.y - min_y - r) * inv_h));
+        const int max_cy = min(GRID_ROWS - 1, (int)ceilf((p.y - min_y + r) * inv_h));
+        if (min_cx >= GRID_COLS || max_cx < 0 || min_cy >= GRID_ROWS || max_cy < 0 || max_cx < min_cx || max_cy < min_cy) return;
+        const int ncy = max_cy - min_cy + 1, ncell = (max_cx - min_cx + 1) * ncy;
+        const uint32_t magic = s_magic[ncy];
+        const uint4* d1p = reinterpret_cast<const uint4*>(desc1 + (o + i1) * 32);
+        const uint4 da = d1p[0], db = d1p[1];
+        for (int c = lane; c < ncell; c += 64) {
+            const int qx = (int)(((uint32_t)c * magic) >> 20);
+            const int cell = (min_cx + qx) * GRID_ROWS + min_cy + (c - qx * ncy);
+            const int ke = s_start[cell + 1];
+            for (int k = s_start[cell]; k < ke; k++) {
+                const int i2 = sorted2[k];
+                const float2 q = pos2[i2];
+                if (!(fabsf(q.x - p.x) < r && fabsf(q.y - p.y) < r)) continue;
+                const uint4* d2p = reinterpret_cast<const uint4*>(desc2 + (o + i2) * 32);
+                const uint4 x = d2p[0], y = d2p[1];
+                const unsigned dist = __popc(x.x ^ da.x) + __popc(x.y ^ da.y) + __popc(x.z ^ da.z) + __popc(x.w ^ da.w) +
+                                      __popc(y.x ^ db.x) + __popc(y.y ^ db.y) + __popc(y.z ^ db.z) + __popc(y.w ^ db.w);
+                body(i2, cell, dist);
+            }
+        }
+    };
+
+    // ---- phase A: candidate lists, one wave per F1 keypoint
+    for (int i1 = wv; i1 < n1; i1 += MP_WAVES) {
+        if (!__builtin_amdgcn_readfirstlane((int)lvl0[i1])) continue;
+        unsigned long long b1 = ~0ull, b2 = ~0ull;             // per lane: its two smallest keys, and how many it saw
+        int seen = 0;
+        for_candidates(i1, [&](int i2, int cell, unsigned dist) {
+            // a candidate beyond TH_LOW is no acceptable best, and as a second best it matters only
+            // if some acceptable best fails the ratio test against it
+            if (dist > MT_TH_LOW && (float)MT_TH_LOW < (float)dist * nnratio) return;
+            const unsigned long long key = ((unsigned long long)dist << 40) | ((unsigned long long)cell << 20) | (unsigned)i2;
+            seen++;
+            if (key < b1) { b2 = b1; b1 = key; }
+            else if (key < b2) b2 = key;
+        });
+        uint32_t e[MP_LIST];
+#pragma unroll
+        for (int q = 0; q < MP_LIST; q++) e[q] = MP_END;
+        int used = 0;
+#pragma unroll
+        for (int q = 0; q < MP_LIST; q++) {
+            const unsigned long long m = wave_min_u64(b1);
+            if (m == ~0ull) break;
+            e[q] = (uint32_t)((m >> 40) << 16) | (uint32_t)(m & 0xFFFF);
+            bool dry = false;
+            if (b1 == m) { used++; b1 = b2; b2 = ~0ull; dry = used == 2 && seen > 2; }
+            if (__ballot(dry)) { if (q + 1 < MP_LIST) e[q + 1] = MP_NONE; break; }
+        }
+        if (lane == 0) *reinterpret_cast<uint4*>(&list1[MP_LIST * i1]) = make_uint4(e[0], e[1], e[2], e[3]);
+    }
+    __syncthreads();
+
+    // ---- phase B: the reference's loop order, one wave, scalar control flow on LDS state
+    if (wv == 0) {
+        for (int i1 = 0; i1 < n1; i1++) {
+            if (!__builtin_amdgcn_readfirstlane((int)lvl0[i1])) continue;
+            int bestDist = 0x7FFFFFFF, bestDist2 = 0x7FFFFFFF, bestIdx2 = -1;
+            bool decided = false;
+            uint32_t term = MP_NONE, last_real = MP_NONE;      // how the list ended (MP_NONE also stands for "all slots used")
+            for (int q = 0; q < MP_LIST; q++) {
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)list1[MP_LIST * i1 + q]);
+                if (c >= MP_END) { term = c; break; }
+                last_real = c;
+                const int d = (int)(c >> 16), i2 = (int)(c & 0xFFFF);
+                if (__builtin_amdgcn_readfirstlane((int)matched_dist[i2]) <= d) continue;   // src/ORBmatcher.cc:441-442
+                if (bestIdx2 < 0) { bestDist = d; bestIdx2 = i2; }
+                else { bestDist2 = d; decided = true; break; }
+            }
+            if (!decided) {
+                if (term == MP_END) decided = true;            // the list was complete: what was found is all there is
+                else if (bestIdx2 >= 0 && last_real != MP_NONE && (float)bestDist < (float)(int)(last_real >> 16) * nnratio)
+                    decided = true;                            // every unlisted candidate lies at or beyond the last listed distance
+            }
+            if (!decided) {
+                // search again with the rule applied: exact best (distance, cell, index) and second-best distance
+                unsigned long long best = ~0ull;
+                unsigned second = 0x7FFFFFFFu;
+                for_candidates(i1, [&](int i2, int cell, unsigned dist) {
+                    if ((unsigned)matched_dist[i2] <= dist) return;
+                    const unsigned long long key = ((unsigned long long)dist << 40) | ((unsigned long long)cell << 20) | (unsigned)i2;
+                    if (key < best) { second = min(second, best == ~0ull ? 0x7FFFFFFFu : (unsigned)(best >> 40)); best = key; }
+                    else second = min(second, dist);
+                });
+                const unsigned long long wbest = wave_min_u64(best);
+                if (wbest == ~0ull) continue;
+                unsigned other = best == wbest ? second : min(second, best == ~0ull ? 0x7FFFFFFFu : (unsigned)(best >> 40));
+#pragma unroll
+                for (int s = 32; s > 0; s >>= 1) other = min(other, (unsigned)__shfl_xor((int)other, s, 64));
+                bestDist = (int)(wbest >> 40); bestIdx2 = (int)(wbest & 0xFFFFF); bestDist2 = (int)other;
+            }
+            if (bestIdx2 < 0) continue;
+            if (bestDist <= MT_TH_LOW && (float)bestDist < (float)bestDist2 * nnratio) {   // src/ORBmatcher.cc:456-458
+                if (lane == 0) {
+                    const int old = matches21[bestIdx2];
+                    if (old != 0xFFFF) m12[old] = -1;          // the earlier owner loses the match
+                    m12[i1] = bestIdx2;
+                    matches21[bestIdx2] = (uint16_t)i1;
+                    matched_dist[bestIdx2] = (uint16_t)bestDist;
+                    taken1[i1] = (uint16_t)bestIdx2;
+                    bin1[i1] = 0xFE;
+                }
+            }
+        }
+    }
+    __syncthreads();                                           // wave 0's stores to m12 are complete and visible to the workgroup
+    if (check_orientation) {
+        const float factor = 1.0f / MT_HISTO;
+        for (int i = tid; i < n1; i += MP_THREADS) {
+            if (bin1[i] != 0xFE) continue;
+            float rot = K1[i].angle - K2[taken1[i]].angle;     // src/ORBmatcher.cc:466-473
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == MT_HISTO) bin = 0;
+            bin1[i] = (uint8_t)bin;
+            atomicAdd(&s_hist[bin], 1);
+        }
+        __syncthreads();
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;   // ComputeThreeMaxima (src/ORBmatcher.cc:1566-1607)
+        for (int i = 0; i < MT_HISTO; i++) {
+            const int s = s_hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = tid; i < n1; i += MP_THREADS) {
+            const int b = bin1[i];
+            if (b < 0xFE && b != ind1 && b != ind2 && b != ind3) m12[i] = -1;   // src/ORBmatcher.cc:494-507
+        }
+    }
+    // vbPrevMatched follows the matches (src/ORBmatcher.cc:511-514); count them
+    int count = 0;
+    for (int i = tid; i < n1; i += MP_THREADS) {
+        const int m = m12[i];                                  // written by wave 0 or by this same thread
+        if (m >= 0) { prev[i] = make_float2(K2[m].x, K2[m].y); count++; }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) count += __shfl_xor(count, s, 64);
+    if (lane == 0) s_tmp[wv] = (uint32_t)count;
+    __syncthreads();
+    if (tid == 0) {
+        int all = 0;
+        for (int w = 0; w < MP_WAVES; w++) all += (int)s_tmp[w];
+        nmatches_out[f] = all;
+    }
+}

@@ -1058,14 +1058,25 @@ int orbhip_search_for_initialization_batch_device(orbhip_extractor* e, int nfram
     if (lds > 160 * 1024 - 512) { e->err = "too many keypoints per frame for the on-chip matcher state"; return ORBHIP_ERR_CAPACITY; }
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
-    if (lds > 64 * 1024)
-        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_init), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const float inv_w = static_cast<float>(GRID_COLS) / (bounds[1] - bounds[0]);
     const float inv_h = static_cast<float>(GRID_ROWS) / (bounds[3] - bounds[2]);
-    hipLaunchKernelGGL(k_search_init, dim3(nframes), dim3(64), lds, s,
-                       reinterpret_cast<const GridKp*>(d_kp_un1), d_desc1, d_cnt1, reinterpret_cast<const GridKp*>(d_kp_un2), d_desc2,
-                       d_cnt2, cap, bounds[0], bounds[2], inv_w, inv_h, (float)window_size, nnratio, check_orientation,
-                       reinterpret_cast<float2*>(d_prev_matched), d_matches12, d_nmatches);
+    // the 16-wave kernel with candidate lists when its state fits (140 KB: about 3900 keypoints per frame), else one wave per pair
+    const size_t lds_par = (size_t)MI_LDS_PER_KP * cap + 16;
+    if (lds_par <= 140 * 1024) {
+        if (lds_par > 40 * 1024)
+            HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_init_par), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_par));
+        hipLaunchKernelGGL(k_search_init_par, dim3(nframes), dim3(MP_THREADS), lds_par, s,
+                           reinterpret_cast<const GridKp*>(d_kp_un1), d_desc1, d_cnt1, reinterpret_cast<const GridKp*>(d_kp_un2), d_desc2,
+                           d_cnt2, cap, bounds[0], bounds[2], inv_w, inv_h, (float)window_size, nnratio, check_orientation,
+                           reinterpret_cast<float2*>(d_prev_matched), d_matches12, d_nmatches);
+    } else {
+        if (lds > 64 * 1024)
+            HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_init), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_search_init, dim3(nframes), dim3(64), lds, s,
+                           reinterpret_cast<const GridKp*>(d_kp_un1), d_desc1, d_cnt1, reinterpret_cast<const GridKp*>(d_kp_un2), d_desc2,
+                           d_cnt2, cap, bounds[0], bounds[2], inv_w, inv_h, (float)window_size, nnratio, check_orientation,
+                           reinterpret_cast<float2*>(d_prev_matched), d_matches12, d_nmatches);
+    }
     HIP_TRY(e, hipGetLastError());
     return ORBHIP_OK;
 }
