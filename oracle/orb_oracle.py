@@ -110,7 +110,7 @@ class OracleExtractor:
     def extract(self, img):
         img = np.ascontiguousarray(img, dtype=np.uint8)
         h, w = img.shape
-        cap = self.nfeatures + 4 * self.nlevels + 64
+        cap = self.nfeatures + 68 * self.nlevels + 64      # a level can keep 4 nodes per initial node whatever its quota
         kp = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         n = C.c_int(0)

@@ -861,34 +861,35 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {   // cv::fas
     return a;
 }
 
-// cosf / sinf of an angle in [0, 2*pi] as correctly rounded floats: evaluated in double (argument
-// reduced by multiples of pi/2 held as a two-term constant, then the classic degree-13 / degree-14
-// minimax kernels on [-pi/4, pi/4], error ~1e-16) and rounded once. libm's float routines return
-// the correctly rounded value in all but vanishingly rare cases, so this matches them.
-__device__ __forceinline__ void sincos_rounded(float x, float* c_out, float* s_out) {
-    const double xd = (double)x;
-    const double kf = rint(xd * 0.63661977236758134308);
-    const int k = (int)kf;
-    double r = fma(-kf, 1.57079632679489655800e+00, xd);
-    r = fma(-kf, 6.12323399573676603587e-17, r);
-    const double z = r * r;
-    const double sp = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
-                                                  2.75573137070700676789e-06), -1.98412698298579493134e-04),
-                                    8.33333333332248946124e-03), -1.66666666666666324348e-01);
-    const double sn = fma(r * z, sp, r);
-    const double cp = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
-                                                  -2.75573143513906633035e-07), 2.48015872894767294178e-05),
-                                    -1.38888888888741095749e-03), 4.16666666666666019037e-02);
-    const double cs = fma(z * z, cp, fma(z, -0.5, 1.0));
-    double c, s;
-    switch (k & 3) {
-        case 0: c = cs; s = sn; break;
-        case 1: c = -sn; s = cs; break;
-        case 2: c = -cs; s = -sn; break;
-        default: c = sn; s = -cs; break;
+// cosf / sinf of an angle in [0, 2*pi] exactly as glibc 2.28+ computes them (sysdeps/ieee754/flt-32/
+// s_sinf.c, s_cosf.c, sincosf.h: argument reduction by multiples of pi/2 and two short polynomials,
+// all in double, one rounding to float). The reference calls cosf / sinf (src/ORBextractor.cc:113-114)
+// and a last-bit difference can flip the rounding of a rotated test point, so the library's
+// arithmetic is restated operation by operation; a host program that ran this restatement against
+// libm over every float in [2^-15, 2*pi] found no difference, with or without fused multiply-adds.
+__device__ __forceinline__ void sincos_rounded(float y, float* c_out, float* s_out) {
+    const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10,
+                 c4 = 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    double x = (double)y;
+    int n = 0;
+    if (!(fabsf(y) < 0x1.921FB6p-1f)) {                        // reduce_fast
+        const double r = x * hpi_inv;
+        n = ((int)r + 0x800000) >> 24;
+        x = x - (double)n * hpi;
     }
-    *c_out = (float)c;
-    *s_out = (float)s;
+    const double sgn = ((n + 1) & 2) ? -1.0 : 1.0;             // sign[n & 3] = {1, -1, -1, 1}
+    const double xs = x * sgn, x2 = x * x;
+    // sinf_poly, even quadrant
+    const double x3 = xs * x2, sp1 = s2 + x2 * s3, x7 = x3 * x2, sp = xs + x3 * s1;
+    const double sn = sp + x7 * sp1;
+    // sinf_poly, odd quadrant (the table for quadrants 2 and 3 holds the negated coefficients)
+    const double x4 = x2 * x2, cp2 = c3 + x2 * c4, cp1 = c0 + x2 * c1, x6 = x4 * x2, cp = cp1 + x4 * c2;
+    const double cs0 = cp + x6 * cp2;
+    const double cs = (n & 2) ? -cs0 : cs0;
+    *s_out = (float)((n & 1) ? cs : sn);
+    *c_out = (float)((n & 1) ? sn : cs);
 }
 
 __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ plan,
