@@ -132,6 +132,12 @@ int orbhip_pyramid_copy(orbhip_extractor* e, int frame, int level, uint8_t* dst,
 typedef struct orbhip_candidate { int x, y, response; } orbhip_candidate;
 int orbhip_debug_candidates(orbhip_extractor* e, int frame, int level, orbhip_candidate* out, int cap);
 
+/* Diagnostics for parity tests: the cosine and sine the descriptor kernel uses for its rotation (the
+ * reference calls cosf / sinf of the keypoint angle in radians, src/ORBextractor.cc:113-114) for the
+ * `count` floats whose bit patterns start at first_bits, written to device arrays; asynchronous on
+ * `stream` (NULL: the handle's). A test compares them with the host C library over [0, 2*pi]. */
+int orbhip_debug_sincos(orbhip_extractor* e, uint32_t first_bits, uint32_t count, float* d_cos, float* d_sin, void* stream);
+
 /* Per-kernel device time of the last batch call, measured with HIP events on the stream the
  * kernels ran on. Enable first; names[i] / ms[i] are filled up to `cap` entries; returns the
  * number of kernel classes. Enabling adds event records (and a wait in this call) only. */

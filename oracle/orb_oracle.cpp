@@ -1254,6 +1254,19 @@ int orbo_search_by_projection(const orbo_keypoint* k_last, const float* world_la
     return nmatches;
 }
 
+/* cosf / sinf of the host C library, as the reference's computeOrbDescriptor calls them
+ * (src/ORBextractor.cc:113-114), for the floats whose bit patterns are first_bits .. first_bits+count-1. */
+void orbo_libm_sincos(uint32_t first_bits, uint32_t count, float* out_cos, float* out_sin) {
+    for (uint32_t i = 0; i < count; i++) {
+        const uint32_t u = first_bits + i;
+        float x;
+        std::memcpy(&x, &u, sizeof x);
+        volatile float arg = x;                                /* no compile-time folding, no sincosf pairing */
+        out_cos[i] = cosf(arg);
+        out_sin[i] = sinf(arg);
+    }
+}
+
 /* cv::remap(src, dst, map1, map2, INTER_LINEAR, BORDER_CONSTANT, Scalar()) for an 8-bit single-channel
  * image and CV_32FC1 maps (the rectification of reference Examples/Stereo/stereo_euroc.cc:136-137),
  * OpenCV 2.4 .. 3.x imgproc/src/imgwarp.cpp: the maps become fixed point with INTER_BITS = 5

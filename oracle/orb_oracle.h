@@ -119,6 +119,9 @@ int orbo_search_for_initialization(const orbo_keypoint* k1, const uint8_t* d1, i
                                    float* prev_matched, int windowSize, float mfNNratio, int mbCheckOrientation,
                                    int* matches12);
 
+/* The host C library's cosf / sinf (what src/ORBextractor.cc:113-114 calls) for `count` consecutive
+ * float bit patterns. */
+void orbo_libm_sincos(uint32_t first_bits, uint32_t count, float* out_cos, float* out_sin);
 /* cv::remap(src, dst, map1, map2, INTER_LINEAR) with constant border 0 for an 8-bit gray image and
  * CV_32FC1 maps of size dw x dh (Examples/Stereo/stereo_euroc.cc:136-137). */
 void orbo_remap_linear(const uint8_t* src, int sw, int sh, size_t sstride, const float* map_x, const float* map_y,

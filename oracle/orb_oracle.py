@@ -83,6 +83,7 @@ def lib():
         L.orbo_projection_level_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int]
         L.orbo_remap_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                         C.c_void_p, C.c_size_t]
+        L.orbo_libm_sincos.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orbo_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
@@ -337,3 +338,11 @@ def extract_batch_mt(params, imgs, nthreads):
     dt = lib().orbo_extract_batch_mt(nfeat, sf, nl, ini, mn, BLUR_LEGACY, _ptr(imgs), f, w, h,
                                      imgs.strides[1], imgs.strides[0], nthreads, counts.ctypes.data_as(C.POINTER(C.c_int)))
     return dt, counts
+
+
+def libm_sincos(first_bits, count):
+    """(cos, sin) float32 arrays of the host C library for `count` consecutive float bit patterns."""
+    c = np.empty(count, np.float32)
+    s = np.empty(count, np.float32)
+    lib().orbo_libm_sincos(int(first_bits), int(count), _ptr(c), _ptr(s))
+    return c, s

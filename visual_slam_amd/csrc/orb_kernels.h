@@ -892,6 +892,18 @@ __device__ __forceinline__ void sincos_rounded(float y, float* c_out, float* s_o
     *c_out = (float)((n & 1) ? sn : cs);
 }
 
+// Diagnostic: sincos_rounded of the floats whose bit patterns are first_bits .. first_bits+count-1,
+// so that a test can compare the device arithmetic with the host's cosf / sinf over a whole range.
+__global__ __launch_bounds__(256) void k_debug_sincos(unsigned first_bits, unsigned count,
+                                                      float* __restrict__ out_cos, float* __restrict__ out_sin) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    float c, s;
+    sincos_rounded(__uint_as_float(first_bits + i), &c, &s);
+    out_cos[i] = c;
+    out_sin[i] = s;
+}
+
 __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ plan,
                                                   const uint8_t* __restrict__ pyr,
                                                   const LevelKp* __restrict__ lvl_kp,

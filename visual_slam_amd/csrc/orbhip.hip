@@ -1144,6 +1144,15 @@ int orbhip_set_rectification(orbhip_extractor* e, const float* map_x, const floa
     return ORBHIP_OK;
 }
 
+int orbhip_debug_sincos(orbhip_extractor* e, uint32_t first_bits, uint32_t count, float* d_cos, float* d_sin, void* stream) {
+    if (!e || !d_cos || !d_sin || count == 0 || count > (1u << 30)) return ORBHIP_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    hipLaunchKernelGGL(k_debug_sincos, dim3((count + 255u) / 256u), dim3(256), 0, s, first_bits, count, d_cos, d_sin);
+    HIP_TRY(e, hipGetLastError());
+    return ORBHIP_OK;
+}
+
 int orbhip_projection_level_mode(const float* Tcw_cur, const float* Tcw_last, float mb, int mono) {
     if (!Tcw_cur || !Tcw_last) return ORBHIP_ERR_ARG;
     // twc = -Rcw^T tcw, tlc = Rlw twc + tlw (src/ORBmatcher.cc:1330-1335): CV_32F matrix products,

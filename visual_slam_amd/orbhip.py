@@ -35,7 +35,7 @@ EXPORTS = [
     "orbhip_image_bounds", "orbhip_undistort_grid", "orbhip_undistort_grid_batch_device",
     "orbhip_search_for_initialization", "orbhip_search_for_initialization_batch_device",
     "orbhip_search_by_projection", "orbhip_search_by_projection_batch_device", "orbhip_projection_level_mode",
-    "orbhip_set_rectification",
+    "orbhip_set_rectification", "orbhip_debug_sincos",
 ]
 
 
@@ -102,6 +102,7 @@ def lib():
                                                                vp, vp, vp]
         L.orbhip_projection_level_mode.argtypes = [vp, vp, C.c_float, C.c_int]
         L.orbhip_set_rectification.argtypes = [vp, vp, vp, C.c_int, C.c_int]
+        L.orbhip_debug_sincos.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]
         L.orbhip_stereo_match.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, ip]
         L.orbhip_stereo_match_batch_device.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float,
                                                        vp, vp, vp, vp]
