@@ -271,6 +271,38 @@ int orbhip_search_by_projection(orbhip_extractor* e, const orbhip_keypoint* kp_l
  * Host only. */
 int orbhip_projection_level_mode(const float* Tcw_cur, const float* Tcw_last, float mb, int mono);
 
+/* ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, const float th)
+ * (src/ORBmatcher.cc:46-127, called by Tracking::SearchLocalPoints) on plain arrays.
+ * A map point is described by what that function reads from it: the fields Frame::isInFrustum
+ * (src/Frame.cc:294-350) left in the MapPoint and two flags.
+ *   proj_x, proj_y, proj_xr  mTrackProjX, mTrackProjY, mTrackProjXR
+ *   view_cos                 mTrackViewCos          level   mnTrackScaleLevel
+ *   flags                    bit 0: mbTrackInView && !isBad(); bit 1: Observations() > 0
+ * A map point whose level is outside [0, nlevels) is ignored (the reference would index
+ * mvScaleFactors out of range). Per frame: cap_mp slots of map points with their descriptors
+ * (GetDescriptor(), 32 bytes each) and d_cnt_mp[f] of them in use, in the order of vpMapPoints;
+ * cap_kp slots of keypoints (mvKeysUn: x, y, octave are read), descriptors, d_uright (mvuRight, NULL:
+ * monocular, all -1), d_occupied (1 where F.mvpMapPoints[idx] holds a point with Observations() > 0 on
+ * entry, NULL: none) and d_cnt_kp[f]. bounds = {mnMinX, mnMaxX, mnMinY, mnMaxY} (host array, read
+ * during the call); mvScaleFactors are the handle's; nnratio is the matcher's mfNNratio.
+ * Output: d_match[f][idx] = index of the map point the reference assigns to F.mvpMapPoints[idx]
+ * (the last one, if several), -1 where it assigns none; d_nmatches[f] = the returned count.
+ * Asynchronous on `stream` (NULL: the handle's). One workgroup per frame; 17 bytes of on-chip state
+ * per map point slot and 18 per keypoint slot must fit 140 KB, else ORBHIP_ERR_CAPACITY. */
+typedef struct orbhip_track_point {
+    float proj_x, proj_y, proj_xr, view_cos;
+    int32_t level, flags;
+} orbhip_track_point;
+int orbhip_search_map_points_batch_device(orbhip_extractor* e, int nframes, int cap_mp, const orbhip_track_point* d_mp,
+                                          const uint8_t* d_desc_mp, const int* d_cnt_mp, int cap_kp,
+                                          const orbhip_keypoint* d_kp, const uint8_t* d_desc, const float* d_uright,
+                                          const uint8_t* d_occupied, const int* d_cnt_kp, const float* bounds, float th,
+                                          float nnratio, int* d_match, int* d_nmatches, void* stream);
+/* The same for one frame with host arrays (n1 map points, n2 keypoints); waits for the result. */
+int orbhip_search_map_points(orbhip_extractor* e, const orbhip_track_point* mp, const uint8_t* desc_mp, int n1,
+                             const orbhip_keypoint* kp, const uint8_t* desc, const float* uright, const uint8_t* occupied, int n2,
+                             const float* bounds, float th, float nnratio, int* match, int* nmatches);
+
 const char* orbhip_strerror(int code);
 const char* orbhip_last_error(const orbhip_extractor* e);
 

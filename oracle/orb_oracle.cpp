@@ -1254,6 +1254,112 @@ int orbo_search_by_projection(const orbo_keypoint* k_last, const float* world_la
     return nmatches;
 }
 
+/* ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, const float th)
+ * (src/ORBmatcher.cc:46-127; the matcher of Tracking::SearchLocalPoints) with RadiusByViewingCos
+ * (:129-135) on plain arrays. mp[i] holds what the function reads from vpMapPoints[i]: mTrackProjX,
+ * mTrackProjY, mTrackProjXR, mTrackViewCos, mnTrackScaleLevel (the fields Frame::isInFrustum,
+ * src/Frame.cc:294-350, leaves there) and flags (bit 0: mbTrackInView && !isBad(), bit 1:
+ * Observations() > 0); desc_mp its GetDescriptor(). Frame, n2 keypoints: k = mvKeysUn, desc =
+ * mDescriptors, uright = mvuRight (NULL: all -1), occupied[idx] = "F.mvpMapPoints[idx] holds a point
+ * with Observations() > 0" on entry (NULL: none does). match[idx] receives the index of the map
+ * point assigned to F.mvpMapPoints[idx] (-1: none assigned here). Returns nmatches. */
+int orbo_search_map_points(const orbo_track_point* mp, const uint8_t* desc_mp, int n1, const orbo_keypoint* k,
+                           const uint8_t* desc, const float* uright, const uint8_t* occupied, int n2,
+                           const float* bounds, const float* scale_factors, int nlevels, float th, float mfNNratio, int* match) {
+    const int COLS = 64, ROWS = 48, TH_HIGH = 100;
+    const float mnMinX = bounds[0], mnMaxX = bounds[1], mnMinY = bounds[2], mnMaxY = bounds[3];
+    const float wInv = static_cast<float>(COLS) / (mnMaxX - mnMinX);
+    const float hInv = static_cast<float>(ROWS) / (mnMaxY - mnMinY);
+    std::vector<std::vector<size_t>> mGrid((size_t)COLS * ROWS);
+    for (int i = 0; i < n2; i++) {
+        const int posX = (int)std::round((k[i].x - mnMinX) * wInv);
+        const int posY = (int)std::round((k[i].y - mnMinY) * hInv);
+        if (posX < 0 || posX >= COLS || posY < 0 || posY >= ROWS) continue;
+        mGrid[(size_t)posX * ROWS + posY].push_back((size_t)i);
+    }
+    auto GetFeaturesInArea = [&](float x, float y, float r, int minLevel, int maxLevel) {   /* src/Frame.cc:351-401 */
+        std::vector<size_t> vIndices;
+        const int nMinCellX = std::max(0, (int)std::floor((x - mnMinX - r) * wInv));
+        if (nMinCellX >= COLS) return vIndices;
+        const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((x - mnMinX + r) * wInv));
+        if (nMaxCellX < 0) return vIndices;
+        const int nMinCellY = std::max(0, (int)std::floor((y - mnMinY - r) * hInv));
+        if (nMinCellY >= ROWS) return vIndices;
+        const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((y - mnMinY + r) * hInv));
+        if (nMaxCellY < 0) return vIndices;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                const std::vector<size_t>& vCell = mGrid[(size_t)ix * ROWS + iy];
+                for (size_t j = 0; j < vCell.size(); j++) {
+                    const orbo_keypoint& kpUn = k[vCell[j]];
+                    if (bCheckLevels) {
+                        if (kpUn.octave < minLevel) continue;
+                        if (maxLevel >= 0 && kpUn.octave > maxLevel) continue;
+                    }
+                    const float distx = kpUn.x - x, disty = kpUn.y - y;
+                    if (std::fabs(distx) < r && std::fabs(disty) < r) vIndices.push_back(vCell[j]);
+                }
+            }
+        return vIndices;
+    };
+    auto DescriptorDistance = [](const uint8_t* a, const uint8_t* b) {   /* src/ORBmatcher.cc:1611-1627 */
+        int dist = 0;
+        for (int i = 0; i < 8; i++) {
+            uint32_t pa, pb;
+            std::memcpy(&pa, a + 4 * i, 4); std::memcpy(&pb, b + 4 * i, 4);
+            unsigned int v = pa ^ pb;
+            v = v - ((v >> 1) & 0x55555555);
+            v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+            dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+        }
+        return dist;
+    };
+    auto RadiusByViewingCos = [](float viewCos) -> float { if (viewCos > 0.998) return 2.5; else return 4.0; };
+    /* F.mvpMapPoints[idx]: -2 = a point from before the call with observations, -1 = none or one without, >= 0 = map point of this call */
+    std::vector<int> holder((size_t)n2);
+    for (int i = 0; i < n2; i++) { holder[i] = (occupied && occupied[i]) ? -2 : -1; match[i] = -1; }
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    for (int iMP = 0; iMP < n1; iMP++) {
+        const orbo_track_point& pMP = mp[iMP];
+        if (!(pMP.flags & 1)) continue;                        /* !mbTrackInView or isBad() */
+        const int nPredictedLevel = pMP.level;
+        if (nPredictedLevel < 0 || nPredictedLevel >= nlevels) continue;   /* outside mvScaleFactors: undefined in the reference */
+        float r = RadiusByViewingCos(pMP.view_cos);
+        if (bFactor) r *= th;
+        const std::vector<size_t> vIndices = GetFeaturesInArea(pMP.proj_x, pMP.proj_y, r * scale_factors[nPredictedLevel],
+                                                               nPredictedLevel - 1, nPredictedLevel);
+        if (vIndices.empty()) continue;
+        const uint8_t* MPdescriptor = desc_mp + 32 * (size_t)iMP;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (size_t idx : vIndices) {
+            if (holder[idx] == -2 || (holder[idx] >= 0 && (mp[holder[idx]].flags & 2))) continue;
+            const float ur = uright ? uright[idx] : -1.0f;
+            if (ur > 0) {
+                const float er = std::fabs(pMP.proj_xr - ur);
+                if (er > r * scale_factors[nPredictedLevel]) continue;
+            }
+            const int dist = DescriptorDistance(MPdescriptor, desc + 32 * idx);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist;
+                bestLevel2 = bestLevel; bestLevel = k[idx].octave;
+                bestIdx = (int)idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = k[idx].octave;
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
+            holder[bestIdx] = iMP;
+            match[bestIdx] = iMP;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
+
 /* cosf / sinf of the host C library, as the reference's computeOrbDescriptor calls them
  * (src/ORBextractor.cc:113-114), for the floats whose bit patterns are first_bits .. first_bits+count-1. */
 void orbo_libm_sincos(uint32_t first_bits, uint32_t count, float* out_cos, float* out_sin) {

@@ -119,6 +119,11 @@ int orbo_search_for_initialization(const orbo_keypoint* k1, const uint8_t* d1, i
                                    float* prev_matched, int windowSize, float mfNNratio, int mbCheckOrientation,
                                    int* matches12);
 
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:46-127). */
+typedef struct orbo_track_point { float proj_x, proj_y, proj_xr, view_cos; int32_t level, flags; } orbo_track_point;
+int orbo_search_map_points(const orbo_track_point* mp, const uint8_t* desc_mp, int n1, const orbo_keypoint* k,
+                           const uint8_t* desc, const float* uright, const uint8_t* occupied, int n2,
+                           const float* bounds, const float* scale_factors, int nlevels, float th, float mfNNratio, int* match);
 /* The host C library's cosf / sinf (what src/ORBextractor.cc:113-114 calls) for `count` consecutive
  * float bit patterns. */
 void orbo_libm_sincos(uint32_t first_bits, uint32_t count, float* out_cos, float* out_sin);

@@ -83,6 +83,8 @@ def lib():
         L.orbo_projection_level_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int]
         L.orbo_remap_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                         C.c_void_p, C.c_size_t]
+        L.orbo_search_map_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
         L.orbo_libm_sincos.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orbo_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         _lib = L
@@ -346,3 +348,22 @@ def libm_sincos(first_bits, count):
     s = np.empty(count, np.float32)
     lib().orbo_libm_sincos(int(first_bits), int(count), _ptr(c), _ptr(s))
     return c, s
+
+
+TRACK_DTYPE = np.dtype([("proj_x", np.float32), ("proj_y", np.float32), ("proj_xr", np.float32), ("view_cos", np.float32),
+                        ("level", np.int32), ("flags", np.int32)])
+
+
+def search_map_points(mp, desc_mp, kp, desc, uright, occupied, bounds, scale_factors, th, nnratio=0.8):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th): returns (match, nmatches) with match[idx] = index of the
+    map point assigned to keypoint idx, or -1."""
+    mp = np.ascontiguousarray(mp, TRACK_DTYPE); kp = np.ascontiguousarray(kp, KP_DTYPE)
+    d1 = np.ascontiguousarray(desc_mp, np.uint8); d2 = np.ascontiguousarray(desc, np.uint8)
+    ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+    oc = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    m = np.full(max(len(kp), 1), -1, np.int32)
+    n = lib().orbo_search_map_points(_ptr(mp), _ptr(d1), len(mp), _ptr(kp), _ptr(d2), None if ur is None else _ptr(ur),
+                                     None if oc is None else _ptr(oc), len(kp), _ptr(np.ascontiguousarray(bounds, np.float32)),
+                                     _ptr(sf), len(sf), float(th), float(nnratio), _ptr(m))
+    return m[:len(kp)], n

@@ -1,0 +1,158 @@
+"""ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (reference src/ORBmatcher.cc:46-127,
+the matcher behind Tracking::SearchLocalPoints): oracle properties on a synthetic local map, and GPU
+parity. The map is made of the keypoints of an earlier view of the same scene (an image shifted by a
+known amount), so a map point's projection is its old position plus the shift, plus some jitter."""
+import numpy as np
+import pytest
+
+from visual_slam_amd import synth
+
+KITTI = (718.856, 718.856, 607.1928, 185.2157, 0.0, 0.0, 0.0, 0.0, 0.0)
+TUM1 = (517.306408, 516.469215, 318.643040, 255.313989, 0.262383, -0.953104, -0.005358, 0.002628, 1.163314)
+
+
+def shifted(img, dx, dy):
+    out = img.copy()
+    h, w = img.shape
+    out[max(dy, 0):h + min(dy, 0), max(dx, 0):w + min(dx, 0)] = img[max(-dy, 0):h + min(-dy, 0), max(-dx, 0):w + min(-dx, 0)]
+    return out
+
+
+def scenario(w, h, index, dx, dy, cam, stereo=False, copies=1, seed=11, prm=(2000, 1.2, 8, 20, 7), occupied_frac=0.1,
+             observed_frac=0.8, jitter=1.5):
+    from oracle import orb_oracle as O
+    a = synth.frame("blocks", w, h, index)
+    b = shifted(a, dx, dy)
+    e = O.OracleExtractor(*prm)
+    k1, d1 = e.extract(a)
+    k2, d2 = e.extract(b)
+    bounds = O.image_bounds(cam, w, h)
+    u1 = O.undistort_grid(cam, bounds, k1)[0]
+    u2 = O.undistort_grid(cam, bounds, k2)[0]
+    rng = np.random.default_rng(seed)
+    n1 = len(u1) * copies
+    src = np.tile(np.arange(len(u1)), copies)
+    rng.shuffle(src)                                                   # vpMapPoints is in no spatial order
+    mp = np.zeros(n1, O.TRACK_DTYPE)
+    mp["proj_x"] = u1["x"][src] + dx + rng.normal(0, jitter, n1)
+    mp["proj_y"] = u1["y"][src] + dy + rng.normal(0, jitter, n1)
+    mbf, Z = 0.5 * cam[0], 6.0
+    mp["proj_xr"] = mp["proj_x"] - mbf / Z
+    mp["view_cos"] = np.where(rng.random(n1) < 0.5, 0.9995, 0.93)
+    mp["level"] = np.clip(u1["octave"][src] + (rng.random(n1) < 0.3), 0, prm[2] - 1)   # the predicted level: the old one or one coarser
+    mp["flags"] = (rng.random(n1) < 0.9).astype(np.int32) | ((rng.random(n1) < observed_frac).astype(np.int32) << 1)
+    desc_mp = d1[src].copy()
+    flip = rng.random(desc_mp.shape) < 0.02                            # the map's descriptor is not this view's
+    desc_mp ^= (flip * (1 << rng.integers(0, 8, desc_mp.shape))).astype(np.uint8)
+    uright = None
+    if stereo:
+        uright = (u2["x"] - mbf / Z).astype(np.float32)
+        uright[rng.random(len(u2)) < 0.3] = -1.0
+        uright[rng.random(len(u2)) < 0.1] += 40.0                      # a right coordinate that contradicts the depth
+    occupied = (rng.random(len(u2)) < occupied_frac).astype(np.uint8)
+    return dict(mp=mp, desc_mp=desc_mp, src=src, u1=u1, u2=u2, d2=d2, uright=uright, occupied=occupied, bounds=bounds,
+                sf=e.table(0), dx=dx, dy=dy)
+
+
+def run_oracle(s, th, nnratio=0.8, occupied=True):
+    from oracle import orb_oracle as O
+    return O.search_map_points(s["mp"], s["desc_mp"], s["u2"], s["d2"], s["uright"], s["occupied"] if occupied else None,
+                               s["bounds"], s["sf"], th, nnratio)
+
+
+def run_device(ex, s, th, nnratio=0.8, occupied=True):
+    from visual_slam_amd import orbhip
+    return orbhip.SearchLocalPoints(ex, s["mp"], s["desc_mp"], s["u2"], s["d2"], s["uright"], s["occupied"] if occupied else None,
+                                    s["bounds"], th, nnratio)
+
+
+def test_oracle_matches_the_local_map_where_it_projects():
+    s = scenario(640, 480, 81, 6, -4, KITTI)
+    m, n = run_oracle(s, 3)
+    got = m >= 0
+    assert n > 300 and got.sum() <= n
+    mp = s["mp"][m[got]]
+    assert np.all(mp["flags"] & 1)                                     # only points in view are matched
+    assert not np.any(got & (s["occupied"] != 0))                      # keypoints that hold an observed point are left alone
+    oct2 = s["u2"]["octave"][got]
+    assert np.all((oct2 == mp["level"]) | (oct2 == mp["level"] - 1))    # GetFeaturesInArea(.., level - 1, level)
+    r = np.where(mp["view_cos"] > 0.998, 2.5, 4.0) * 3 * s["sf"][mp["level"]]
+    assert np.all(np.abs(s["u2"]["x"][got] - mp["proj_x"]) < r) and np.all(np.abs(s["u2"]["y"][got] - mp["proj_y"]) < r)
+    # most assignments are the right ones: the map point came from the keypoint at this place in the other view
+    ex = s["u2"]["x"][got] - s["u1"]["x"][s["src"][m[got]]] - s["dx"]
+    ey = s["u2"]["y"][got] - s["u1"]["y"][s["src"][m[got]]] - s["dy"]
+    tol = 2.0 * s["sf"][oct2]
+    assert np.mean((np.abs(ex) <= tol) & (np.abs(ey) <= tol)) > 0.75    # TH_HIGH = 100 lets some wrong neighbours through
+    # th == 1 takes the window as it is (no factor), a wider window finds at least as many
+    m1, n1 = run_oracle(s, 1)
+    assert 0 < n1 <= n
+    # a stricter ratio only removes matches whose second best lies on the same level
+    ms, ns = run_oracle(s, 3, nnratio=0.5)
+    assert ns <= n
+    # points that are not in view contribute nothing
+    none = dict(s, mp=s["mp"].copy())
+    none["mp"]["flags"] &= ~1
+    assert run_oracle(none, 3)[1] == 0
+
+
+def test_oracle_observed_points_block_later_ones():
+    # every map point three times: the copies want the same keypoints
+    s = scenario(640, 480, 82, 3, 2, KITTI, copies=3, prm=(1000, 1.2, 8, 20, 7), observed_frac=1.0, occupied_frac=0.0)
+    m, n = run_oracle(s, 3)
+    assert n == (m >= 0).sum() and n > 300                             # observed points are never overwritten
+    s0 = dict(s, mp=s["mp"].copy())
+    s0["mp"]["flags"] &= ~2                                            # none observed: later copies overwrite earlier ones
+    m0, n0 = run_oracle(s0, 3)
+    assert n0 > (m0 >= 0).sum()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cam,w,h,dx,dy,stereo,th,nnratio,copies", [
+    (KITTI, 1241, 376, 6, 2, True, 3, 0.8, 1),
+    (TUM1, 640, 480, -7, 5, False, 1, 0.8, 2),
+    (KITTI, 752, 480, 4, -3, True, 5, 0.7, 3),
+    (KITTI, 640, 480, 2, 2, False, 3, 0.9, 1),
+])
+def test_hip_search_local_points_matches_oracle(cam, w, h, dx, dy, stereo, th, nnratio, copies):
+    from visual_slam_amd import orbhip
+    s = scenario(w, h, 83, dx, dy, cam, stereo=stereo, copies=copies, prm=(1500, 1.2, 8, 20, 7))
+    om, on = run_oracle(s, th, nnratio)
+    ex = orbhip.ORBextractor(1500, 1.2, 8, 20, 7)
+    gm, gn = run_device(ex, s, th, nnratio)
+    assert on > 100 and gn == on
+    assert np.array_equal(gm, om)
+
+
+@pytest.mark.gpu
+def test_hip_search_local_points_contested_and_edge_cases():
+    from visual_slam_amd import orbhip
+    ex = orbhip.ORBextractor(1000, 1.2, 8, 20, 7)
+    # heavy contention: four copies of every point, half of them observed, coarse jitter
+    s = scenario(640, 480, 84, 5, 0, KITTI, copies=4, prm=(1000, 1.2, 8, 20, 7), observed_frac=0.5, jitter=3.0)
+    for th in (1, 3, 8):
+        om, on = run_oracle(s, th)
+        gm, gn = run_device(ex, s, th)
+        assert gn == on and np.array_equal(gm, om), th
+    assert on > (om >= 0).sum()
+    # no occupancy array, no map points, no keypoints
+    om, on = run_oracle(s, 3, occupied=False)
+    gm, gn = run_device(ex, s, 3, occupied=False)
+    assert gn == on and np.array_equal(gm, om)
+    e0 = dict(s, mp=s["mp"][:0], desc_mp=s["desc_mp"][:0])
+    gm, gn = run_device(ex, e0, 3)
+    assert gn == 0 and np.all(gm == -1)
+    e1 = dict(s, u2=s["u2"][:0], d2=s["d2"][:0], occupied=s["occupied"][:0])
+    gm, gn = run_device(ex, e1, 3)
+    assert gn == 0 and len(gm) == 0
+    # levels outside the pyramid are ignored by both
+    bad = dict(s, mp=s["mp"].copy())
+    bad["mp"]["level"][::7] = 9
+    bad["mp"]["level"][3::11] = -1
+    om, on = run_oracle(bad, 3)
+    gm, gn = run_device(ex, bad, 3)
+    assert gn == on and np.array_equal(gm, om)
+    # more state than the chip holds is refused, not truncated
+    import ctypes as C
+    with pytest.raises(orbhip.OrbHipError):
+        big = np.zeros(9000, orbhip.TRACK_DTYPE)
+        orbhip.SearchLocalPoints(ex, big, np.zeros((9000, 32), np.uint8), s["u2"], s["d2"], None, None, s["bounds"], 3)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random-parameter sweep of the device paths next to the extraction (rectification, the two
+"""Random-parameter sweep of the device paths next to the extraction (rectification, the three
 matchers) against the oracle. One-off robustness tool: prints the failing draws, exit status 1 if any.
 
 Usage: python tools/fuzz_next_rows.py [--cases 60] [--seed 1]
@@ -97,6 +97,27 @@ def main():
         gm12, gp, gn2 = orbhip.SearchForInitialization(ex, u1, d1, u2, d2, bounds, prev, win, ratio, ori)
         if gn2 != on2 or not np.array_equal(gm12, om12) or not np.array_equal(gp.view(np.uint32), op.view(np.uint32)):
             bad += 1; print(tag, "INITIALIZATION MISMATCH", gn2, on2)
+        # the local-map matcher: the first view's keypoints (several copies, shuffled) as map points
+        copies = int(rng.integers(1, 4))
+        src = np.tile(np.arange(len(u1)), copies); rng.shuffle(src)
+        mp = np.zeros(len(src), O.TRACK_DTYPE)
+        jit = float(rng.uniform(0, 4))
+        mp["proj_x"] = u1["x"][src] + dx + rng.normal(0, jit, len(src)); mp["proj_y"] = u1["y"][src] + dy + rng.normal(0, jit, len(src))
+        mp["proj_xr"] = mp["proj_x"] - 0.4 * fx / Z
+        mp["view_cos"] = rng.choice(np.array([0.9995, 0.998, 0.93, 0.9981], np.float32), len(src))
+        mp["level"] = u1["octave"][src] + rng.integers(-1, 2, len(src))             # now and then outside the pyramid
+        mp["flags"] = (rng.random(len(src)) < 0.9).astype(np.int32) | ((rng.random(len(src)) < rng.random()).astype(np.int32) << 1)
+        dmp = d1[src].copy()
+        dmp ^= ((rng.random(dmp.shape) < rng.uniform(0, 0.08)) * (1 << rng.integers(0, 8, dmp.shape))).astype(np.uint8)
+        occ = (rng.random(len(u2)) < rng.uniform(0, 0.3)).astype(np.uint8) if rng.random() < 0.7 else None
+        thl = float(rng.choice([1, 3, 5, 8])); ratio = float(rng.choice([0.6, 0.8, 0.9]))
+        try:
+            gm3, gn3 = orbhip.SearchLocalPoints(ex, mp, dmp, u2, d2, ur, occ, bounds, thl, ratio)
+        except orbhip.OrbHipError as e:
+            print(tag, "local map refused:", e); continue
+        om3, on3 = O.search_map_points(mp, dmp, u2, d2, ur, occ, bounds, sf, thl, ratio)
+        if gn3 != on3 or not np.array_equal(gm3, om3):
+            bad += 1; print(tag, "LOCAL MAP MISMATCH", gn3, on3, int((gm3 != om3).sum()))
     print("fuzz: %d cases, %d mismatches" % (args.cases, bad))
     sys.exit(1 if bad else 0)
 

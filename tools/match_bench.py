@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--th", type=float, default=15.0)
     ap.add_argument("--cpu-pairs", type=int, default=16)
     ap.add_argument("--observed", type=float, default=0.8, help="fraction of map points with observations")
+    ap.add_argument("--local-copies", type=int, default=2, help="local map = this many copies of the last frame's keypoints")
     args = ap.parse_args()
     n, w, h = args.pairs, args.width, args.height
     dev = torch.device("cuda", 0)
@@ -119,6 +120,63 @@ def main():
             ok = ok and on == hn[i] and np.array_equal(om, hm[i, :hc2[i]])
         out["oracle_parity_first_pairs"] = bool(ok)
         out["cpu_oracle_pairs_per_s_one_thread"] = round(m / t, 1)
+    except ImportError:
+        pass
+    print(json.dumps(out))
+
+    # ---- ORBmatcher::SearchByProjection(F, vpMapPoints, th): a local map of local_copies x the last frame's keypoints
+    K = args.local_copies
+    hc1 = c1.cpu().numpy(); hk1 = k1.cpu().numpy(); hd1 = d1.cpu().numpy()
+    cap_mp = K * cap
+    mp = np.zeros((n, cap_mp), orbhip.TRACK_DTYPE)
+    dmp = np.zeros((n, cap_mp, 32), np.uint8)
+    cnt_mp = np.zeros(n, np.int32)
+    for i in range(n):
+        c = int(hc1[i])
+        src = np.tile(np.arange(c), K); rng.shuffle(src)
+        dx, dy = motion[i]
+        mp["proj_x"][i, :len(src)] = hu1[i, src, 0] + dx + rng.normal(0, 1.5, len(src))
+        mp["proj_y"][i, :len(src)] = hu1[i, src, 1] + dy + rng.normal(0, 1.5, len(src))
+        mp["proj_xr"][i, :len(src)] = mp["proj_x"][i, :len(src)] - 0.5 * fx / Z
+        mp["view_cos"][i, :len(src)] = np.where(rng.random(len(src)) < 0.5, 0.9995, 0.93)
+        mp["level"][i, :len(src)] = hk1[i, src].view(orbhip.KP_DTYPE)["octave"].reshape(-1)
+        mp["flags"][i, :len(src)] = 1 | ((rng.random(len(src)) < args.observed).astype(np.int32) << 1)
+        dmp[i, :len(src)] = hd1[i, src]
+        cnt_mp[i] = len(src)
+    with torch.cuda.stream(stream):
+        d_mp = torch.from_numpy(mp.view(np.uint8).reshape(n, cap_mp, 24)).to(dev); d_dmp = torch.from_numpy(dmp).to(dev)
+        d_cmp = torch.from_numpy(cnt_mp).to(dev)
+    stream.synchronize()
+
+    def step_local():
+        orbhip.search_map_points_batch_device(ex, n, cap_mp, d_mp.data_ptr(), d_dmp.data_ptr(), d_cmp.data_ptr(), cap, u2.data_ptr(),
+                                              d2.data_ptr(), None, None, c2.data_ptr(), bounds, 3.0, 0.8, match.data_ptr(), nm.data_ptr(),
+                                              stream=sp)
+    step_local(); stream.synchronize()
+    with torch.cuda.stream(stream):
+        e0.record(stream)
+        for _ in range(args.steps):
+            step_local()
+        e1.record(stream)
+    stream.synchronize()
+    ms = e0.elapsed_time(e1) / args.steps
+    hm, hn = match.cpu().numpy(), nm.cpu().numpy()
+    out = {"op": "SearchByProjection(F, vpMapPoints)", "frames": n, "image": [w, h], "th": 3.0, "map_points_per_frame": float(cnt_mp.mean()),
+           "ms_per_batch": round(ms, 3), "frames_per_s": round(n / ms * 1e3, 1), "mean_matches": float(hn.mean())}
+    try:
+        from oracle import orb_oracle as O
+        hu2, hd2, hc2 = u2.cpu().numpy(), d2.cpu().numpy(), c2.cpu().numpy()
+        sf = np.array(ex.GetScaleFactors(), np.float32)
+        m = min(args.cpu_pairs, n)
+        ok, t = True, 0.0
+        for i in range(m):
+            a2 = np.zeros(hc2[i], orbhip.KP_DTYPE); a2[:] = hu2[i, :hc2[i]].view(orbhip.KP_DTYPE).reshape(-1)
+            t0 = time.perf_counter()
+            om, on = O.search_map_points(mp[i, :cnt_mp[i]], dmp[i, :cnt_mp[i]], a2, hd2[i, :hc2[i]], None, None, bounds, sf, 3.0, 0.8)
+            t += time.perf_counter() - t0
+            ok = ok and on == hn[i] and np.array_equal(om, hm[i, :hc2[i]])
+        out["oracle_parity_first_frames"] = bool(ok)
+        out["cpu_oracle_frames_per_s_one_thread"] = round(m / t, 1)
     except ImportError:
         pass
     print(json.dumps(out))

@@ -680,3 +680,209 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_init_par(const GridKp* __
         nmatches_out[f] = all;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th)
+// (reference src/ORBmatcher.cc:46-127; Tracking::SearchLocalPoints, src/Tracking.cc) on plain
+// arrays: every local map point that Frame::isInFrustum marked visible (its projection, predicted
+// pyramid level and viewing cosine are inputs, as the reference reads them from the MapPoint) is
+// matched against the frame's keypoints inside a window whose size depends on the viewing angle
+// (RadiusByViewingCos, src/ORBmatcher.cc:129-135) and the predicted level; the best candidate is
+// accepted when it is close enough and, if the second best lies on the same level, distinctly
+// better than it.
+//
+// The loop over the map points is sequential only through one rule: a keypoint that holds a point
+// with observations is skipped, and an accepted match puts such a point there. Occupancy only ever
+// grows, so the work is split as in k_search_proj: first every map point lists, in parallel, its
+// best few candidates under the occupancy of the call's start, in the reference's order of
+// preference (distance, cell, index: strict comparisons make the first of equal distances the best
+// and the second of them the second best). Then one wave walks the map points in order: the first
+// two listed candidates that are still free are the reference's best and second best; a list that
+// ends before it decides is replaced by a search under the current occupancy.
+// Candidates that can decide nothing are left out of the lists: beyond TH_HIGH none is an
+// acceptable best, and as a second best it matters only if an acceptable best fails the ratio test
+// against it.
+// ------------------------------------------------------------------------------------------------
+struct TrackPt { float x, y, xr, view_cos; int level, flags; };   // flags: 1 = mbTrackInView and not bad, 2 = Observations() > 0
+
+#define ML_LDS_PER_MP 17      // dynamic LDS bytes per map point slot
+#define ML_LDS_PER_KP 18      // and per keypoint slot
+
+__global__ __launch_bounds__(MP_THREADS) void k_search_map(const TrackPt* __restrict__ mp, const uint8_t* __restrict__ desc1,
+                                                           const int* __restrict__ cnt1, int cap1,
+                                                           const GridKp* __restrict__ kp2, const uint8_t* __restrict__ desc2,
+                                                           const float* __restrict__ uright2, const uint8_t* __restrict__ occupied2,
+                                                           const int* __restrict__ cnt2, int cap2, float min_x, float min_y,
+                                                           float inv_w, float inv_h, float th, float nnratio, ScaleTab sf, int nlevels,
+                                                           int* __restrict__ match2, int* __restrict__ nmatches_out) {
+    extern __shared__ __align__(16) uint8_t ml_smem[];
+    uint32_t* list1 = reinterpret_cast<uint32_t*>(ml_smem);                  // map point: MP_LIST x (distance << 16 | keypoint), best first
+    float2* pos2 = reinterpret_cast<float2*>(list1 + MP_LIST * (size_t)cap1);  // keypoint: position
+    float* ur2 = reinterpret_cast<float*>(pos2 + cap2);                      // mvuRight
+    uint16_t* sorted2 = reinterpret_cast<uint16_t*>(ur2 + cap2);             // keypoint indices bucketed by grid cell
+    uint16_t* cell2 = sorted2 + cap2;                                        // grid cell, 0xFFFF = outside
+    uint8_t* oct2 = reinterpret_cast<uint8_t*>(cell2 + cap2);                // octave
+    uint8_t* occ2 = oct2 + cap2;                                             // holds a point with observations
+    uint8_t* st1 = occ2 + cap2;                                              // map point: 1 usable | 2 observed
+    __shared__ uint32_t s_cur[GRID_CELLS];
+    __shared__ uint16_t s_start[GRID_CELLS + 2];
+    __shared__ uint32_t s_magic[GRID_ROWS + 1];
+    __shared__ uint32_t s_tmp[MP_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, f = blockIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t o1 = (size_t)f * cap1, o2 = (size_t)f * cap2;
+    const int n1 = min(cnt1[f], cap1), n2 = min(cnt2[f], cap2);
+    const TrackPt* P = mp + o1;
+    const GridKp* K2 = kp2 + o2;
+    int* m2 = match2 + o2;
+
+    for (int c = tid; c < GRID_CELLS; c += MP_THREADS) s_cur[c] = 0;
+    if (tid >= 1 && tid <= GRID_ROWS) s_magic[tid] = ((1u << 20) + tid - 1) / tid;
+    __syncthreads();
+    for (int i = tid; i < n2; i += MP_THREADS) {
+        const GridKp k = K2[i];
+        const int cell = grid_cell(k.x, k.y, min_x, min_y, inv_w, inv_h);
+        pos2[i] = make_float2(k.x, k.y);
+        ur2[i] = uright2 ? uright2[o2 + i] : -1.0f;
+        cell2[i] = (uint16_t)(cell < 0 ? 0xFFFF : cell);
+        oct2[i] = (uint8_t)k.octave;
+        occ2[i] = occupied2 ? (uint8_t)(occupied2[o2 + i] != 0) : (uint8_t)0;
+        m2[i] = -1;
+        if (cell >= 0) atomicAdd(&s_cur[cell], 1u);
+    }
+    for (int i = tid; i < n1; i += MP_THREADS) {
+        const int fl = P[i].flags, lv = P[i].level;
+        st1[i] = (uint8_t)(((fl & 1) && lv >= 0 && lv < nlevels) ? (1 | (fl & 2)) : 0);
+        list1[MP_LIST * i] = MP_END;
+    }
+    __syncthreads();
+    const uint32_t total = mp_block_excl_scan(s_cur, GRID_CELLS, s_tmp);
+    for (int c = tid; c < GRID_CELLS; c += MP_THREADS) s_start[c] = (uint16_t)s_cur[c];
+    if (tid == 0) s_start[GRID_CELLS] = (uint16_t)total;
+    __syncthreads();
+    for (int i = tid; i < n2; i += MP_THREADS) {
+        const int cell = cell2[i];
+        if (cell != 0xFFFF) sorted2[atomicAdd(&s_cur[cell], 1u)] = (uint16_t)i;
+    }
+    __syncthreads();
+
+    // The two smallest keys  distance << 40 | cell << 20 | index  every lane finds among its share of
+    // the free candidates of map point i (lanes over the cells of the window), and how many it saw.
+    // prune: leave out the candidates that can decide nothing (see above).
+    auto scan = [&](int i, bool prune, unsigned long long& b1, unsigned long long& b2, int& seen) __attribute__((always_inline)) {
+        b1 = b2 = ~0ull;
+        seen = 0;
+        const TrackPt t = P[i];                                // wave-uniform
+        float r = (double)t.view_cos > 0.998 ? 2.5f : 4.0f;    // RadiusByViewingCos
+        if (th != 1.0f) r *= th;                               // src/ORBmatcher.cc:50,66-67
+        r = r * sf.v[t.level];
+        const int lo = t.level - 1, hi = t.level;              // GetFeaturesInArea(.., nPredictedLevel-1, nPredictedLevel)
+        const int min_cx = max(0, (int)floorf((t.x - min_x - r) * inv_w));
+        const int max_cx = min(GRID_COLS - 1, (int)ceilf((t.x - min_x + r) * inv_w));
+        const int min_cy = max(0, (int)floorf((t.y - min_y - r) * inv_h));
+        const int max_cy = min(GRID_ROWS - 1, (int)ceilf((t.y - min_y + r) * inv_h));
+        if (min_cx >= GRID_COLS || max_cx < 0 || min_cy >= GRID_ROWS || max_cy < 0 || max_cx < min_cx || max_cy < min_cy) return;
+        const int ncy = max_cy - min_cy + 1, ncell = (max_cx - min_cx + 1) * ncy;
+        const uint32_t magic = s_magic[ncy];
+        const uint4* d1p = reinterpret_cast<const uint4*>(desc1 + (o1 + i) * 32);
+        const uint4 da = d1p[0], db = d1p[1];
+        for (int c = lane; c < ncell; c += 64) {
+            const int qx = (int)(((uint32_t)c * magic) >> 20);
+            const int cell = (min_cx + qx) * GRID_ROWS + min_cy + (c - qx * ncy);
+            const int ke = s_start[cell + 1];
+            for (int k = s_start[cell]; k < ke; k++) {
+                const int i2 = sorted2[k];
+                const int oc = oct2[i2];
+                if (oc < lo || oc > hi) continue;
+                const float2 q = pos2[i2];
+                if (!(fabsf(q.x - t.x) < r && fabsf(q.y - t.y) < r)) continue;
+                if (occ2[i2]) continue;                        // src/ORBmatcher.cc:88-90
+                const float u2 = ur2[i2];
+                if (u2 > 0 && fabsf(t.xr - u2) > r) continue;  // src/ORBmatcher.cc:92-97
+                const uint4* d2p = reinterpret_cast<const uint4*>(desc2 + (o2 + i2) * 32);
+                const uint4 x = d2p[0], y = d2p[1];
+                const unsigned dist = __popc(x.x ^ da.x) + __popc(x.y ^ da.y) + __popc(x.z ^ da.z) + __popc(x.w ^ da.w) +
+                                      __popc(y.x ^ db.x) + __popc(y.y ^ db.y) + __popc(y.z ^ db.z) + __popc(y.w ^ db.w);
+                if (prune && dist > MP_TH_HIGH && !((float)MP_TH_HIGH > nnratio * (float)dist)) continue;
+                const unsigned long long key = ((unsigned long long)dist << 40) | ((unsigned long long)cell << 20) | (unsigned)i2;
+                seen++;
+                if (key < b1) { b2 = b1; b1 = key; }
+                else if (key < b2) b2 = key;
+            }
+        }
+    };
+
+    // ---- phase A: candidate lists, one wave per map point
+    for (int i = wv; i < n1; i += MP_WAVES) {
+        if (!(__builtin_amdgcn_readfirstlane((int)st1[i]) & 1)) continue;
+        unsigned long long b1, b2;
+        int seen;
+        scan(i, true, b1, b2, seen);
+        uint32_t e[MP_LIST];
+#pragma unroll
+        for (int q = 0; q < MP_LIST; q++) e[q] = MP_END;
+        int used = 0;
+#pragma unroll
+        for (int q = 0; q < MP_LIST; q++) {
+            const unsigned long long m = wave_min_u64(b1);
+            if (m == ~0ull) break;
+            e[q] = (uint32_t)((m >> 40) << 16) | (uint32_t)(m & 0xFFFF);
+            bool dry = false;                                  // a lane that handed out both keys it kept and saw more: its third might come next
+            if (b1 == m) { used++; b1 = b2; b2 = ~0ull; dry = used == 2 && seen > 2; }
+            if (__ballot(dry)) { if (q + 1 < MP_LIST) e[q + 1] = MP_NONE; break; }
+        }
+        if (lane == 0) *reinterpret_cast<uint4*>(&list1[MP_LIST * i]) = make_uint4(e[0], e[1], e[2], e[3]);
+    }
+    __syncthreads();
+
+    // ---- phase B: the reference's loop order, one wave, scalar control flow on LDS state
+    int made = 0;
+    if (wv == 0) {
+        for (int i = 0; i < n1; i++) {
+            const int st = __builtin_amdgcn_readfirstlane((int)st1[i]);
+            if (!(st & 1)) continue;
+            uint32_t best = MP_NONE, second = MP_NONE;         // distance << 16 | keypoint
+            bool decided = false;
+            uint32_t term = MP_NONE, last_real = MP_NONE;      // how the list ended (MP_NONE also stands for "all slots used")
+            for (int q = 0; q < MP_LIST; q++) {
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)list1[MP_LIST * i + q]);
+                if (c >= MP_END) { term = c; break; }
+                last_real = c;
+                if (__builtin_amdgcn_readfirstlane((int)occ2[c & 0xFFFF])) continue;
+                if (best == MP_NONE) {
+                    best = c;
+                    if ((c >> 16) > MP_TH_HIGH) { decided = true; break; }   // nothing closer is free: no match
+                } else { second = c; decided = true; break; }
+            }
+            if (!decided) {
+                if (term == MP_END) decided = true;            // the list was complete: what was found is all there is
+                else if (best != MP_NONE && last_real != MP_NONE && !((float)(int)(best >> 16) > nnratio * (float)(int)(last_real >> 16)))
+                    decided = true;                            // whatever the second best is, it lies at or beyond the last listed distance
+            }
+            if (!decided) {
+                unsigned long long b1, b2;
+                int seen;
+                scan(i, false, b1, b2, seen);
+                const unsigned long long k1 = wave_min_u64(b1);
+                if (b1 == k1) b1 = b2;                          // keys are unique: one lane holds it
+                const unsigned long long k2 = wave_min_u64(b1);
+                best = k1 == ~0ull ? MP_NONE : (uint32_t)((k1 >> 40) << 16) | (uint32_t)(k1 & 0xFFFF);
+                second = k2 == ~0ull ? MP_NONE : (uint32_t)((k2 >> 40) << 16) | (uint32_t)(k2 & 0xFFFF);
+            }
+            if (best == MP_NONE) continue;
+            const int bestDist = (int)(best >> 16), bestIdx = (int)(best & 0xFFFF);
+            if (bestDist > MP_TH_HIGH) continue;               // src/ORBmatcher.cc:116
+            if (second != MP_NONE) {
+                const int lv1 = __builtin_amdgcn_readfirstlane((int)oct2[bestIdx]);
+                const int lv2 = __builtin_amdgcn_readfirstlane((int)oct2[second & 0xFFFF]);
+                if (lv1 == lv2 && (float)bestDist > nnratio * (float)(int)(second >> 16)) continue;   // src/ORBmatcher.cc:118-119
+            }
+            made++;
+            if (lane == 0) {
+                m2[bestIdx] = i;                               // a point without observations is simply overwritten
+                occ2[bestIdx] = (uint8_t)((st >> 1) & 1);
+            }
+        }
+        if (lane == 0) nmatches_out[f] = made;
+    }
+}

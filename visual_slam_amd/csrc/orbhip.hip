@@ -1258,6 +1258,79 @@ int orbhip_search_by_projection(orbhip_extractor* e, const orbhip_keypoint* kp_l
     return ORBHIP_OK;
 }
 
+int orbhip_search_map_points_batch_device(orbhip_extractor* e, int nframes, int cap_mp, const orbhip_track_point* d_mp,
+                                          const uint8_t* d_desc_mp, const int* d_cnt_mp, int cap_kp,
+                                          const orbhip_keypoint* d_kp, const uint8_t* d_desc, const float* d_uright,
+                                          const uint8_t* d_occupied, const int* d_cnt_kp, const float* bounds, float th,
+                                          float nnratio, int* d_match, int* d_nmatches, void* stream) {
+    if (!e || nframes < 1 || cap_mp < 1 || cap_kp < 1 || cap_kp > 65534 || !d_mp || !d_desc_mp || !d_cnt_mp || !d_kp || !d_desc ||
+        !d_cnt_kp || !bounds || !d_match || !d_nmatches || !(bounds[1] > bounds[0]) || !(bounds[3] > bounds[2]) || !(nnratio > 0.0f))
+        return ORBHIP_ERR_ARG;
+    static_assert(sizeof(orbhip_track_point) == sizeof(TrackPt), "track point layout");
+    const size_t lds = (size_t)ML_LDS_PER_MP * cap_mp + (size_t)ML_LDS_PER_KP * cap_kp + 32;
+    if (lds > 160 * 1024 - 20 * 1024) { e->err = "too many map points and keypoints per frame for the on-chip matcher state"; return ORBHIP_ERR_CAPACITY; }
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    if (lds > 40 * 1024)
+        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_map), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ScaleTab sf;
+    for (int l = 0; l < ORB_MAX_LEVELS; l++) sf.v[l] = e->sf[std::min(l, e->prm.nlevels - 1)];
+    const float inv_w = static_cast<float>(GRID_COLS) / (bounds[1] - bounds[0]);   // src/Frame.cc:128-129
+    const float inv_h = static_cast<float>(GRID_ROWS) / (bounds[3] - bounds[2]);
+    // the map point lists come first in the carve-up and are written 16 bytes at a time: 16 * cap_mp keeps every later array aligned
+    hipLaunchKernelGGL(k_search_map, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const TrackPt*>(d_mp), d_desc_mp, d_cnt_mp,
+                       cap_mp, reinterpret_cast<const GridKp*>(d_kp), d_desc, d_uright, d_occupied, d_cnt_kp, cap_kp, bounds[0], bounds[2],
+                       inv_w, inv_h, th, nnratio, sf, e->prm.nlevels, d_match, d_nmatches);
+    HIP_TRY(e, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_search_map_points(orbhip_extractor* e, const orbhip_track_point* mp, const uint8_t* desc_mp, int n1,
+                             const orbhip_keypoint* kp, const uint8_t* desc, const float* uright, const uint8_t* occupied, int n2,
+                             const float* bounds, float th, float nnratio, int* match, int* nmatches) {
+    if (!e || n1 < 0 || n2 < 0 || !bounds || !nmatches) return ORBHIP_ERR_ARG;
+    if (n2 > 0 && !match) return ORBHIP_ERR_ARG;
+    for (int i = 0; i < n2; i++) match[i] = -1;
+    if (n1 == 0 || n2 == 0) { *nmatches = 0; return ORBHIP_OK; }
+    if (!mp || !desc_mp || !kp || !desc) return ORBHIP_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
+    const size_t tb = up((size_t)n1 * sizeof(orbhip_track_point)), d1b = up((size_t)n1 * 32);
+    const size_t kpb = up((size_t)n2 * sizeof(orbhip_keypoint)), d2b = up((size_t)n2 * 32), ub = up((size_t)n2 * 4), ob = up((size_t)n2);
+    const size_t need = 64 + tb + d1b + kpb + d2b + 2 * ub + ob;
+    if (need > e->d_st_tmp_bytes) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        dfree(e->d_st_tmp);
+        HIP_TRY(e, hipMalloc(&e->d_st_tmp, need));
+        e->d_st_tmp_bytes = need;
+    }
+    uint8_t* p = e->d_st_tmp;
+    int* d_cnt = reinterpret_cast<int*>(p); p += 64;           // [0] n1, [1] n2, [2] matches
+    orbhip_track_point* d_t = reinterpret_cast<orbhip_track_point*>(p); p += tb;
+    uint8_t* d_d1 = p; p += d1b;
+    orbhip_keypoint* d_k = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
+    uint8_t* d_d2 = p; p += d2b;
+    float* d_u = reinterpret_cast<float*>(p); p += ub;
+    int* d_m = reinterpret_cast<int*>(p); p += ub;
+    uint8_t* d_o = p;
+    const int cnt[3] = {n1, n2, 0};
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(d_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_t, mp, (size_t)n1 * sizeof(orbhip_track_point), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_d1, desc_mp, (size_t)n1 * 32, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_k, kp, (size_t)n2 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_d2, desc, (size_t)n2 * 32, hipMemcpyHostToDevice));
+    if (uright) HIP_TRY(e, hipMemcpy(d_u, uright, (size_t)n2 * 4, hipMemcpyHostToDevice));
+    if (occupied) HIP_TRY(e, hipMemcpy(d_o, occupied, (size_t)n2, hipMemcpyHostToDevice));
+    int rc = orbhip_search_map_points_batch_device(e, 1, n1, d_t, d_d1, d_cnt, n2, d_k, d_d2, uright ? d_u : nullptr,
+                                                   occupied ? d_o : nullptr, d_cnt + 1, bounds, th, nnratio, d_m, d_cnt + 2, nullptr);
+    if (rc) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(match, d_m, (size_t)n2 * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(nmatches, d_cnt + 2, sizeof(int), hipMemcpyDeviceToHost));
+    return ORBHIP_OK;
+}
+
 const char* orbhip_strerror(int code) {
     switch (code) {
         case ORBHIP_OK: return "ok";

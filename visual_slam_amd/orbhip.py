@@ -36,6 +36,7 @@ EXPORTS = [
     "orbhip_search_for_initialization", "orbhip_search_for_initialization_batch_device",
     "orbhip_search_by_projection", "orbhip_search_by_projection_batch_device", "orbhip_projection_level_mode",
     "orbhip_set_rectification", "orbhip_debug_sincos",
+    "orbhip_search_map_points", "orbhip_search_map_points_batch_device",
 ]
 
 
@@ -103,6 +104,9 @@ def lib():
         L.orbhip_projection_level_mode.argtypes = [vp, vp, C.c_float, C.c_int]
         L.orbhip_set_rectification.argtypes = [vp, vp, vp, C.c_int, C.c_int]
         L.orbhip_debug_sincos.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]
+        L.orbhip_search_map_points.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, C.c_float, C.c_float, vp, ip]
+        L.orbhip_search_map_points_batch_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp,
+                                                            C.c_float, C.c_float, vp, vp, vp]
         L.orbhip_stereo_match.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, ip]
         L.orbhip_stereo_match_batch_device.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float,
                                                        vp, vp, vp, vp]
@@ -203,6 +207,36 @@ def search_by_projection_batch_device(ex, nframes, cap, d_kp_last, d_world_last,
                                                              d_desc_last, d_cnt_last, d_kp_cur, d_desc_cur, d_uright_cur,
                                                              d_cnt_cur, d_Tcw, d_level_mode, C.byref(prm), d_match_cur,
                                                              d_nmatches, stream))
+
+
+TRACK_DTYPE = np.dtype([("proj_x", np.float32), ("proj_y", np.float32), ("proj_xr", np.float32), ("view_cos", np.float32),
+                        ("level", np.int32), ("flags", np.int32)])                  # orbhip_track_point
+
+
+def SearchLocalPoints(ex, mp, desc_mp, kp, desc, uright, occupied, bounds, th, nnratio=0.8):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th) (reference src/ORBmatcher.cc:46-127, the matcher of
+    Tracking::SearchLocalPoints) on the device. mp: TRACK_DTYPE records of the map points (what Frame::isInFrustum
+    left in them, flags bit 0 = in view and not bad, bit 1 = has observations). Returns (match, nmatches):
+    match[idx] = index of the map point keypoint idx received, or -1."""
+    mp = np.ascontiguousarray(mp, TRACK_DTYPE); kp = np.ascontiguousarray(kp, KP_DTYPE)
+    d1 = np.ascontiguousarray(desc_mp, np.uint8); d2 = np.ascontiguousarray(desc, np.uint8)
+    ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+    oc = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    m = np.full(max(len(kp), 1), -1, np.int32)
+    n = C.c_int(0)
+    ex._check(lib().orbhip_search_map_points(ex._h, _ptr(mp), _ptr(d1), len(mp), _ptr(kp), _ptr(d2), None if ur is None else _ptr(ur),
+                                             None if oc is None else _ptr(oc), len(kp), _ptr(np.ascontiguousarray(bounds, np.float32)),
+                                             float(th), float(nnratio), _ptr(m), C.byref(n)))
+    return m[:len(kp)], n.value
+
+
+def search_map_points_batch_device(ex, nframes, cap_mp, d_mp, d_desc_mp, d_cnt_mp, cap_kp, d_kp, d_desc, d_uright, d_occupied,
+                                   d_cnt_kp, bounds, th, nnratio, d_match, d_nmatches, stream=None):
+    """Raw-pointer batch call of SearchLocalPoints on device-resident frames."""
+    b = np.ascontiguousarray(bounds, np.float32)
+    ex._check(lib().orbhip_search_map_points_batch_device(ex._h, nframes, cap_mp, d_mp, d_desc_mp, d_cnt_mp, cap_kp, d_kp, d_desc,
+                                                          d_uright, d_occupied, d_cnt_kp, _ptr(b), float(th), float(nnratio),
+                                                          d_match, d_nmatches, stream))
 
 
 def ComputeStereoMatches(left, right, kp_l, desc_l, kp_r, desc_r, mb, mbf):
