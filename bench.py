@@ -139,7 +139,8 @@ def main():
     ap.add_argument("--max-batch", type=int, default=0, help="frames per internal pass (0 = library default)")
     ap.add_argument("--workload", default="C4_1080p_2000f", choices=sorted(WORKLOADS))
     ap.add_argument("--kind", default="blocks", choices=["blocks", "noise", "lowc"])
-    ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=-1,
+                    help="frames of the CPU baseline sample (0 = skip; default: the pixels of 256 1080p frames, at most 256 frames: 20-30 s of CPU work)")
     ap.add_argument("--stereo", action="store_true", help="step = left + right extraction + stereo matching of every pair; value = pairs/s")
     ap.add_argument("--rectify", action="store_true", help="rectify every frame through cv::remap-style maps on the way into level 0")
     ap.add_argument("--color", type=int, default=0, choices=[0, 3, 4], help="feed interleaved BGR(A) frames: gray conversion fused into level 0")
@@ -313,6 +314,8 @@ def main():
                                               "kernel_ms_per_step": {k: round(v[0] / 2, 3) for k, v in t1.items()}}
             del ex1
         cpu = None
+        if args.cpu_frames < 0:
+            args.cpu_frames = max(16, min(256, int(256 * (1920 * 1080) / (w * h))))
         if args.cpu_frames > 0 and world == 1:           # the CPU baseline is timed at N = 1 only
             from oracle import orb_oracle   # checker / baseline only, never on the measured GPU path
             from visual_slam_amd import synth

@@ -1,7 +1,8 @@
 """The device entry points chained as a stereo tracking front-end would chain them, on one stream
 and without a host round trip in between: rectification + extraction of both eyes at two time steps,
-stereo matching (reference src/Frame.cc:481-653), undistortion (src/Frame.cc:422-449) and the
-motion-model matcher (src/ORBmatcher.cc:1324-1445) between the two steps. Every stage is compared
+stereo matching (reference src/Frame.cc:481-653), undistortion (src/Frame.cc:422-449), the
+motion-model matcher (src/ORBmatcher.cc:1324-1445) between the two steps and the local-map matcher
+(src/ORBmatcher.cc:46-127) on the second. Every stage is compared
 with the oracle run stage by stage on the host: besides the arithmetic this checks the ordering of
 the calls against each other (streams, workspaces that later passes overwrite)."""
 import numpy as np
@@ -88,9 +89,40 @@ def test_stereo_front_end_chain_matches_oracle_stage_by_stage():
                                              res["L1"][2].data_ptr(), dT.data_ptr(), None, prm_p, match.data_ptr(), nmatch.data_ptr(),
                                              stream=sp)
     stream.synchronize()
+    # Tracking::SearchLocalPoints next: the local map = the points of step 0 twice over (shuffled), projected with
+    # the same motion; keypoints that the motion-model matcher gave an observed point are occupied
+    rng = np.random.default_rng(5)
+    hmatch = match.cpu().numpy()
+    occupied = ((hmatch >= 0) & (np.take_along_axis(flags, np.maximum(hmatch, 0), axis=1) >= 2)).astype(np.uint8)
+    cap_mp = 2 * cap
+    mp = np.zeros((n, cap_mp), orbhip.TRACK_DTYPE)
+    dmp = np.zeros((n, cap_mp, 32), np.uint8)
+    cnt_mp = np.zeros(n, np.int32)
+    hd0 = res["L0"][1].cpu().numpy()
+    for i in range(n):
+        src = np.tile(np.arange(int(hc0[i])), 2); rng.shuffle(src)
+        m = len(src)
+        mp["proj_x"][i, :m] = hu0[i, src, 0] + motion[i][0] + rng.normal(0, 1.0, m)
+        mp["proj_y"][i, :m] = hu0[i, src, 1] + motion[i][1] + rng.normal(0, 1.0, m)
+        mp["proj_xr"][i, :m] = mp["proj_x"][i, :m] - 14.0
+        mp["view_cos"][i, :m] = np.where(rng.random(m) < 0.5, 0.9995, 0.9)
+        mp["level"][i, :m] = hu0[i, src].view(orbhip.KP_DTYPE)["octave"].reshape(-1)
+        mp["flags"][i, :m] = 1 | ((rng.random(m) < 0.7).astype(np.int32) << 1)
+        dmp[i, :m] = hd0[i, src]
+        cnt_mp[i] = m
+    with torch.cuda.stream(stream):
+        d_mp = torch.from_numpy(mp.view(np.uint8).reshape(n, cap_mp, 24)).to(dev)
+        d_dmp, d_cmp, d_occ = (torch.from_numpy(a).to(dev) for a in (dmp, cnt_mp, occupied))
+        lmatch = torch.zeros((n, cap), dtype=torch.int32, device=dev)
+        lnm = torch.zeros((n,), dtype=torch.int32, device=dev)
+    stream.synchronize()
+    orbhip.search_map_points_batch_device(gL, n, cap_mp, d_mp.data_ptr(), d_dmp.data_ptr(), d_cmp.data_ptr(), cap, un["L1"].data_ptr(),
+                                          res["L1"][1].data_ptr(), ur["1"].data_ptr(), d_occ.data_ptr(), res["L1"][2].data_ptr(),
+                                          bounds, 3.0, 0.8, lmatch.data_ptr(), lnm.data_ptr(), stream=sp)
+    stream.synchronize()
 
     # ---- the same chain on the host, stage by stage
-    total_stereo = total_proj = 0
+    total_stereo = total_proj = total_local = 0
     for i in range(n):
         o = {}
         for key, raw in (("L0", L0), ("R0", R0), ("L1", L1), ("R1", R1)):
@@ -118,4 +150,9 @@ def test_stereo_front_end_chain_matches_oracle_stage_by_stage():
         assert int(nmatch[i].item()) == on, i
         assert np.array_equal(match[i, :c1].cpu().numpy(), om), i
         total_proj += on
-    assert total_stereo > 6 * 100 and total_proj > 3 * 30
+        lm, ln = O.search_map_points(mp[i, :cnt_mp[i]], dmp[i, :cnt_mp[i]], u1, o["L1"][2], st["1"][0], occupied[i, :c1], bounds,
+                                     o["L1"][0].table(0), 3.0, 0.8)
+        assert int(lnm[i].item()) == ln, i
+        assert np.array_equal(lmatch[i, :c1].cpu().numpy(), lm), i
+        total_local += ln
+    assert total_stereo > 6 * 100 and total_proj > 3 * 30 and total_local > 3 * 100
