@@ -138,6 +138,11 @@ int orbhip_debug_candidates(orbhip_extractor* e, int frame, int level, orbhip_ca
  * `stream` (NULL: the handle's). A test compares them with the host C library over [0, 2*pi]. */
 int orbhip_debug_sincos(orbhip_extractor* e, uint32_t first_bits, uint32_t count, float* d_cos, float* d_sin, void* stream);
 
+/* Diagnostics for parity tests: the logarithm orbhip_is_in_frustum uses for MapPoint::PredictScale (the
+ * reference calls log() on a float, src/MapPoint.cc:409) for the `count` positive normal floats whose
+ * bit patterns are first_bits + i * stride, written to a device array. */
+int orbhip_debug_logf(orbhip_extractor* e, uint32_t first_bits, uint32_t count, uint32_t stride, float* d_out, void* stream);
+
 /* Per-kernel device time of the last batch call, measured with HIP events on the stream the
  * kernels ran on. Enable first; names[i] / ms[i] are filled up to `cap` entries; returns the
  * number of kernel classes. Enabling adds event records (and a wait in this call) only. */
@@ -302,6 +307,27 @@ int orbhip_search_map_points_batch_device(orbhip_extractor* e, int nframes, int 
 int orbhip_search_map_points(orbhip_extractor* e, const orbhip_track_point* mp, const uint8_t* desc_mp, int n1,
                              const orbhip_keypoint* kp, const uint8_t* desc, const float* uright, const uint8_t* occupied, int n2,
                              const float* bounds, float th, float nnratio, int* match, int* nmatches);
+
+/* Frame::isInFrustum(MapPoint*, viewingCosLimit) (src/Frame.cc:294-350) with MapPoint::PredictScale
+ * (src/MapPoint.cc:401-417) and Get{Min,Max}DistanceInvariance (:372-382) for arrays of map points: the
+ * loop of Tracking::SearchLocalPoints that precedes the search above. Per map point: GetWorldPos(),
+ * GetNormal(), mfMinDistance, mfMaxDistance and flags (bit 0: test this point, i.e. it is not bad and
+ * was not seen by this frame already; bit 1: Observations() > 0, passed through). Per frame: d_pose
+ * = 15 floats, mRcw row-major, mtcw, mOw (Frame::UpdatePoseMatrices). prm: camera, mbf and image
+ * bounds (th and check_orientation are not read); mfLogScaleFactor and mnScaleLevels are the
+ * handle's. d_track[f][i] receives what isInFrustum stores in the MapPoint (flags bit 0 =
+ * mbTrackInView), ready for orbhip_search_map_points_batch_device; d_nvisible[f] (may be NULL) the
+ * number of points in view (nToMatch). Asynchronous on `stream` (NULL: the handle's). */
+typedef struct orbhip_map_point {
+    float pos[3], normal[3], min_distance, max_distance;
+    int32_t flags;
+} orbhip_map_point;
+int orbhip_is_in_frustum_batch_device(orbhip_extractor* e, int nframes, int cap_mp, const orbhip_map_point* d_mp, const int* d_cnt_mp,
+                                      const float* d_pose, const orbhip_projection_params* prm, float viewing_cos_limit,
+                                      orbhip_track_point* d_track, int* d_nvisible, void* stream);
+/* The same for one frame with host arrays; waits for the result. */
+int orbhip_is_in_frustum(orbhip_extractor* e, const orbhip_map_point* mp, int n, const float* pose,
+                         const orbhip_projection_params* prm, float viewing_cos_limit, orbhip_track_point* track, int* nvisible);
 
 const char* orbhip_strerror(int code);
 const char* orbhip_last_error(const orbhip_extractor* e);

@@ -1360,6 +1360,71 @@ int orbo_search_map_points(const orbo_track_point* mp, const uint8_t* desc_mp, i
     return nmatches;
 }
 
+/* Frame::isInFrustum(MapPoint* pMP, float viewingCosLimit) (src/Frame.cc:294-350) for n map points, with
+ * MapPoint::PredictScale (src/MapPoint.cc:401-417) and Get{Min,Max}DistanceInvariance (:372-382).
+ * mp[i]: GetWorldPos(), GetNormal(), mfMinDistance, mfMaxDistance, flags (bit 0: the caller wants it
+ * tested, bit 1: Observations() > 0, passed through). pose = mRcw row-major (9), mtcw (3), mOw (3);
+ * cam = {fx, fy, cx, cy}; bounds = {mnMinX, mnMaxX, mnMinY, mnMaxY}; scale_factor = mfScaleFactor
+ * (mfLogScaleFactor = log of it, the float overload), nlevels = mnScaleLevels. track[i] receives
+ * mTrackProjX, mTrackProjY, mTrackProjXR, mTrackViewCos, mnTrackScaleLevel and flags bit 0 =
+ * mbTrackInView. Returns the number of points in view.
+ * cv::Mat arithmetic as OpenCV performs it for CV_32F: mRcw * P + mtcw through the small-matrix gemm
+ * (float products summed in float, translation added in double), P - mOw per element in float,
+ * cv::norm and Mat::dot of three elements accumulated in double. */
+int orbo_is_in_frustum(const orbo_map_point* mp, int n, const float* pose, const float* cam, float mbf,
+                       const float* bounds, float scale_factor, int nlevels, float viewingCosLimit, orbo_track_point* track) {
+    const float fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3];
+    const float mnMinX = bounds[0], mnMaxX = bounds[1], mnMinY = bounds[2], mnMaxY = bounds[3];
+    const float mfLogScaleFactor = std::log(scale_factor);
+    int nvisible = 0;
+    for (int i = 0; i < n; i++) {
+        orbo_track_point& t = track[i];
+        t.proj_x = t.proj_y = t.proj_xr = t.view_cos = 0.0f; t.level = 0; t.flags = mp[i].flags & 2;
+        if (!(mp[i].flags & 1)) continue;
+        const float* P = mp[i].pos;
+        float Pc[3];
+        for (int r = 0; r < 3; r++) {
+            const float s0 = pose[3 * r] * P[0] + pose[3 * r + 1] * P[1] + pose[3 * r + 2] * P[2];
+            Pc[r] = (float)((double)s0 * 1.0 + (double)pose[9 + r] * 1.0);
+        }
+        const float PcX = Pc[0], PcY = Pc[1], PcZ = Pc[2];
+        if (PcZ < 0.0f) continue;
+        const float invz = 1.0f / PcZ;
+        const float u = fx * PcX * invz + cx;
+        const float v = fy * PcY * invz + cy;
+        if (!(u == u) || !(v == v)) continue;                  /* a point in the camera centre: undefined in the reference */
+        if (u < mnMinX || u > mnMaxX) continue;
+        if (v < mnMinY || v > mnMaxY) continue;
+        const float maxDistance = 1.2f * mp[i].max_distance;
+        const float minDistance = 0.8f * mp[i].min_distance;
+        const float PO[3] = {P[0] - pose[12], P[1] - pose[13], P[2] - pose[14]};
+        double nrm = 0;
+        for (int k = 0; k < 3; k++) { const double e = PO[k]; nrm += e * e; }
+        const float dist = (float)std::sqrt(nrm);
+        if (dist < minDistance || dist > maxDistance) continue;
+        double dot = 0;
+        for (int k = 0; k < 3; k++) dot += (double)PO[k] * mp[i].normal[k];
+        const float viewCos = (float)(dot / dist);
+        if (viewCos < viewingCosLimit) continue;
+        /* MapPoint::PredictScale */
+        const float ratio = mp[i].max_distance / dist;
+        const float c = std::ceil(std::log(ratio) / mfLogScaleFactor);
+        int nScale;
+        if (c >= -2147483648.0f && c < 2147483648.0f) nScale = (int)c;
+        else nScale = -2147483647 - 1;                         /* what the x86 conversion returns out of range */
+        if (nScale < 0) nScale = 0;
+        else if (nScale >= nlevels) nScale = nlevels - 1;
+        t.flags |= 1;
+        t.proj_x = u;
+        t.proj_xr = u - mbf * invz;
+        t.proj_y = v;
+        t.level = nScale;
+        t.view_cos = viewCos;
+        nvisible++;
+    }
+    return nvisible;
+}
+
 /* cosf / sinf of the host C library, as the reference's computeOrbDescriptor calls them
  * (src/ORBextractor.cc:113-114), for the floats whose bit patterns are first_bits .. first_bits+count-1. */
 void orbo_libm_sincos(uint32_t first_bits, uint32_t count, float* out_cos, float* out_sin) {
@@ -1370,6 +1435,18 @@ void orbo_libm_sincos(uint32_t first_bits, uint32_t count, float* out_cos, float
         volatile float arg = x;                                /* no compile-time folding, no sincosf pairing */
         out_cos[i] = cosf(arg);
         out_sin[i] = sinf(arg);
+    }
+}
+
+/* logf of the host C library (what log() of a float resolves to in src/MapPoint.cc:409) for the floats
+ * whose bit patterns are first_bits + i * stride. */
+void orbo_libm_logf(uint32_t first_bits, uint32_t count, uint32_t stride, float* out) {
+    for (uint32_t i = 0; i < count; i++) {
+        const uint32_t u = first_bits + i * stride;
+        float x;
+        std::memcpy(&x, &u, sizeof x);
+        volatile float arg = x;
+        out[i] = std::log(arg);
     }
 }
 

@@ -124,8 +124,13 @@ typedef struct orbo_track_point { float proj_x, proj_y, proj_xr, view_cos; int32
 int orbo_search_map_points(const orbo_track_point* mp, const uint8_t* desc_mp, int n1, const orbo_keypoint* k,
                            const uint8_t* desc, const float* uright, const uint8_t* occupied, int n2,
                            const float* bounds, const float* scale_factors, int nlevels, float th, float mfNNratio, int* match);
+/* Frame::isInFrustum (src/Frame.cc:294-350) for arrays of map points. */
+typedef struct orbo_map_point { float pos[3], normal[3], min_distance, max_distance; int32_t flags; } orbo_map_point;
+int orbo_is_in_frustum(const orbo_map_point* mp, int n, const float* pose, const float* cam, float mbf,
+                       const float* bounds, float scale_factor, int nlevels, float viewingCosLimit, orbo_track_point* track);
 /* The host C library's cosf / sinf (what src/ORBextractor.cc:113-114 calls) for `count` consecutive
  * float bit patterns. */
+void orbo_libm_logf(uint32_t first_bits, uint32_t count, uint32_t stride, float* out);
 void orbo_libm_sincos(uint32_t first_bits, uint32_t count, float* out_cos, float* out_sin);
 /* cv::remap(src, dst, map1, map2, INTER_LINEAR) with constant border 0 for an 8-bit gray image and
  * CV_32FC1 maps of size dw x dh (Examples/Stereo/stereo_euroc.cc:136-137). */

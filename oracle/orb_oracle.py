@@ -85,6 +85,9 @@ def lib():
                                         C.c_void_p, C.c_size_t]
         L.orbo_search_map_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        L.orbo_is_in_frustum.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_int,
+                                         C.c_float, C.c_void_p]
+        L.orbo_libm_logf.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orbo_libm_sincos.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orbo_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         _lib = L
@@ -367,3 +370,24 @@ def search_map_points(mp, desc_mp, kp, desc, uright, occupied, bounds, scale_fac
                                      None if oc is None else _ptr(oc), len(kp), _ptr(np.ascontiguousarray(bounds, np.float32)),
                                      _ptr(sf), len(sf), float(th), float(nnratio), _ptr(m))
     return m[:len(kp)], n
+
+
+MAPPOINT_DTYPE = np.dtype([("pos", np.float32, 3), ("normal", np.float32, 3), ("min_distance", np.float32),
+                           ("max_distance", np.float32), ("flags", np.int32)])
+
+
+def is_in_frustum(mp, pose, cam4, mbf, bounds, scale_factor, nlevels, viewing_cos_limit=0.5):
+    """Frame::isInFrustum for an array of map points: returns (track records, number in view)."""
+    mp = np.ascontiguousarray(mp, MAPPOINT_DTYPE)
+    out = np.zeros(max(len(mp), 1), TRACK_DTYPE)
+    n = lib().orbo_is_in_frustum(_ptr(mp), len(mp), _ptr(np.ascontiguousarray(pose, np.float32).reshape(15)),
+                                 _ptr(np.ascontiguousarray(cam4, np.float32)), float(mbf), _ptr(np.ascontiguousarray(bounds, np.float32)),
+                                 float(np.float32(scale_factor)), int(nlevels), float(viewing_cos_limit), _ptr(out))
+    return out[:len(mp)], n
+
+
+def libm_logf(first_bits, count, stride=1):
+    """float32 logf of the host C library for the float bit patterns first_bits + i * stride."""
+    out = np.empty(count, np.float32)
+    lib().orbo_libm_logf(int(first_bits), int(count), int(stride), _ptr(out))
+    return out

@@ -8,8 +8,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libORBhip.so"
 SOURCES = [CSRC / "orbhip.hip"]
-DEPS = SOURCES + [CSRC / "orb_kernels.h", CSRC / "orb_device.h", CSRC / "orb_fast.h",
-                  PKG.parent / "include" / "orbhip.h", PKG.parent / "include" / "orb_pattern_31.inc"]
+DEPS = SOURCES + sorted(CSRC.glob("*.h")) + [PKG.parent / "include" / "orbhip.h", PKG.parent / "include" / "orb_pattern_31.inc"]
 # -ffp-contract=off: float expressions (scale tables, fastAtan2, the rBRIEF rotation) must round
 # exactly as written, on the host and on the device.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

@@ -19,6 +19,7 @@
 #include "orb_stereo.h"
 #include "orb_grid.h"
 #include "orb_match.h"
+#include "orb_frustum.h"
 
 namespace {
 
@@ -1328,6 +1329,70 @@ int orbhip_search_map_points(orbhip_extractor* e, const orbhip_track_point* mp, 
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     HIP_TRY(e, hipMemcpy(match, d_m, (size_t)n2 * sizeof(int), hipMemcpyDeviceToHost));
     HIP_TRY(e, hipMemcpy(nmatches, d_cnt + 2, sizeof(int), hipMemcpyDeviceToHost));
+    return ORBHIP_OK;
+}
+
+int orbhip_debug_logf(orbhip_extractor* e, uint32_t first_bits, uint32_t count, uint32_t stride, float* d_out, void* stream) {
+    if (!e || !d_out || count == 0 || count > (1u << 30) || stride == 0) return ORBHIP_ERR_ARG;
+    const unsigned long long last = (unsigned long long)first_bits + (unsigned long long)(count - 1) * stride;
+    if (first_bits < 0x00800000u || last >= 0x7f800000ull) return ORBHIP_ERR_ARG;   // positive normal floats only
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    hipLaunchKernelGGL(k_debug_logf, dim3((count + 255u) / 256u), dim3(256), 0, s, first_bits, count, stride, d_out);
+    HIP_TRY(e, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_is_in_frustum_batch_device(orbhip_extractor* e, int nframes, int cap_mp, const orbhip_map_point* d_mp, const int* d_cnt_mp,
+                                      const float* d_pose, const orbhip_projection_params* prm, float viewing_cos_limit,
+                                      orbhip_track_point* d_track, int* d_nvisible, void* stream) {
+    if (!e || nframes < 1 || cap_mp < 1 || !d_mp || !d_cnt_mp || !d_pose || !prm || !d_track) return ORBHIP_ERR_ARG;
+    static_assert(sizeof(orbhip_map_point) == sizeof(MapPt), "map point layout");
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    FrustumArgs a;
+    a.fx = prm->fx; a.fy = prm->fy; a.cx = prm->cx; a.cy = prm->cy; a.mbf = prm->mbf;
+    a.min_x = prm->bounds[0]; a.max_x = prm->bounds[1]; a.min_y = prm->bounds[2]; a.max_y = prm->bounds[3];
+    a.viewing_cos_limit = viewing_cos_limit;
+    a.log_scale_factor = std::log((float)e->scale_factor_d);   // mfLogScaleFactor (src/Frame.cc: log(mfScaleFactor), the float overload)
+    a.nlevels = e->prm.nlevels;
+    if (d_nvisible) HIP_TRY(e, hipMemsetAsync(d_nvisible, 0, (size_t)nframes * sizeof(int), s));
+    hipLaunchKernelGGL(k_in_frustum, dim3((cap_mp + 255) / 256, nframes), dim3(256), 0, s, reinterpret_cast<const MapPt*>(d_mp), d_cnt_mp,
+                       cap_mp, d_pose, a, reinterpret_cast<TrackPt*>(d_track), d_nvisible);
+    HIP_TRY(e, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_is_in_frustum(orbhip_extractor* e, const orbhip_map_point* mp, int n, const float* pose,
+                         const orbhip_projection_params* prm, float viewing_cos_limit, orbhip_track_point* track, int* nvisible) {
+    if (!e || n < 0 || !pose || !prm) return ORBHIP_ERR_ARG;
+    if (nvisible) *nvisible = 0;
+    if (n == 0) return ORBHIP_OK;
+    if (!mp || !track) return ORBHIP_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
+    const size_t mb = up((size_t)n * sizeof(orbhip_map_point)), tb = up((size_t)n * sizeof(orbhip_track_point));
+    const size_t need = 128 + mb + tb;
+    if (need > e->d_st_tmp_bytes) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        dfree(e->d_st_tmp);
+        HIP_TRY(e, hipMalloc(&e->d_st_tmp, need));
+        e->d_st_tmp_bytes = need;
+    }
+    uint8_t* p = e->d_st_tmp;
+    int* d_cnt = reinterpret_cast<int*>(p);                     // [0] n, [1] visible
+    float* d_pose = reinterpret_cast<float*>(p + 64); p += 128;
+    orbhip_map_point* d_m = reinterpret_cast<orbhip_map_point*>(p); p += mb;
+    orbhip_track_point* d_t = reinterpret_cast<orbhip_track_point*>(p);
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(d_cnt, &n, sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_pose, pose, 15 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_m, mp, (size_t)n * sizeof(orbhip_map_point), hipMemcpyHostToDevice));
+    int rc = orbhip_is_in_frustum_batch_device(e, 1, n, d_m, d_cnt, d_pose, prm, viewing_cos_limit, d_t, d_cnt + 1, nullptr);
+    if (rc) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(track, d_t, (size_t)n * sizeof(orbhip_track_point), hipMemcpyDeviceToHost));
+    if (nvisible) HIP_TRY(e, hipMemcpy(nvisible, d_cnt + 1, sizeof(int), hipMemcpyDeviceToHost));
     return ORBHIP_OK;
 }
 

@@ -37,6 +37,7 @@ EXPORTS = [
     "orbhip_search_by_projection", "orbhip_search_by_projection_batch_device", "orbhip_projection_level_mode",
     "orbhip_set_rectification", "orbhip_debug_sincos",
     "orbhip_search_map_points", "orbhip_search_map_points_batch_device",
+    "orbhip_is_in_frustum", "orbhip_is_in_frustum_batch_device", "orbhip_debug_logf",
 ]
 
 
@@ -104,6 +105,9 @@ def lib():
         L.orbhip_projection_level_mode.argtypes = [vp, vp, C.c_float, C.c_int]
         L.orbhip_set_rectification.argtypes = [vp, vp, vp, C.c_int, C.c_int]
         L.orbhip_debug_sincos.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]
+        L.orbhip_debug_logf.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
+        L.orbhip_is_in_frustum.argtypes = [vp, vp, C.c_int, vp, vp, C.c_float, vp, ip]
+        L.orbhip_is_in_frustum_batch_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_float, vp, vp, vp]
         L.orbhip_search_map_points.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, C.c_float, C.c_float, vp, ip]
         L.orbhip_search_map_points_batch_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp,
                                                             C.c_float, C.c_float, vp, vp, vp]
@@ -211,6 +215,28 @@ def search_by_projection_batch_device(ex, nframes, cap, d_kp_last, d_world_last,
 
 TRACK_DTYPE = np.dtype([("proj_x", np.float32), ("proj_y", np.float32), ("proj_xr", np.float32), ("view_cos", np.float32),
                         ("level", np.int32), ("flags", np.int32)])                  # orbhip_track_point
+
+
+MAPPOINT_DTYPE = np.dtype([("pos", np.float32, 3), ("normal", np.float32, 3), ("min_distance", np.float32),
+                           ("max_distance", np.float32), ("flags", np.int32)])        # orbhip_map_point
+
+
+def IsInFrustum(ex, mp, pose, cam4, mbf, bounds, viewing_cos_limit=0.5):
+    """Frame::isInFrustum (reference src/Frame.cc:294-350) for an array of map points (MAPPOINT_DTYPE) on the
+    device. pose: 15 floats, Rcw row-major, tcw, Ow. Returns (TRACK_DTYPE records, number in view)."""
+    mp = np.ascontiguousarray(mp, MAPPOINT_DTYPE)
+    out = np.zeros(max(len(mp), 1), TRACK_DTYPE)
+    prm = projection_params(cam4, mbf, bounds, 0.0, False)
+    n = C.c_int(0)
+    ex._check(lib().orbhip_is_in_frustum(ex._h, _ptr(mp), len(mp), _ptr(np.ascontiguousarray(pose, np.float32).reshape(15)),
+                                         C.byref(prm), float(viewing_cos_limit), _ptr(out), C.byref(n)))
+    return out[:len(mp)], n.value
+
+
+def is_in_frustum_batch_device(ex, nframes, cap_mp, d_mp, d_cnt_mp, d_pose, prm, viewing_cos_limit, d_track, d_nvisible, stream=None):
+    """Raw-pointer batch call of IsInFrustum on device-resident map points (prm: ProjectionParams)."""
+    ex._check(lib().orbhip_is_in_frustum_batch_device(ex._h, nframes, cap_mp, d_mp, d_cnt_mp, d_pose, C.byref(prm),
+                                                      float(viewing_cos_limit), d_track, d_nvisible, stream))
 
 
 def SearchLocalPoints(ex, mp, desc_mp, kp, desc, uright, occupied, bounds, th, nnratio=0.8):
