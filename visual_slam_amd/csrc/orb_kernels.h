@@ -28,25 +28,53 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // skip_hi on), one thread per (row, group), reflecting byte path.
 #define L0_RPT 4                  // rows per thread of the interior copy
 
+// The 16 bytes of group c16 of plane row r through the reflection, byte by byte.
+__device__ __forceinline__ void level0_edge_group(const uint8_t* __restrict__ src_frame, size_t row_stride, uint8_t* __restrict__ plane,
+                                                  const LevelGeom& g, int r, int c16) {
+    const uint8_t* S = src_frame + (size_t)reflect101(r - ORB_OY, g.h) * row_stride;
+    const int x0 = c16 * 16 - ORB_OX;
+    uint32_t o[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        o[d] = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) o[d] |= (uint32_t)S[reflect101(x0 + 4 * d + b, g.w)] << (8 * b);
+    }
+    reinterpret_cast<uint4*>(plane + (size_t)r * g.pitch)[c16] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// Grid x: the blocks of 64 interior groups, then one more block that does the nb border groups of
+// the block's 4 * L0_RPT rows (their latency-bound byte path runs beside the streaming copy).
 __global__ __launch_bounds__(256) void k_level0_interior(const uint8_t* __restrict__ src, size_t row_stride,
                                                          size_t frame_stride, uint8_t* __restrict__ pyr,
-                                                         LevelGeom g, int g_lo, int g_hi) {
+                                                         LevelGeom g, int g_lo, int g_hi, int nb) {
+    const int f = blockIdx.z;
+    uint8_t* D = pyr + g.pyr_off + (size_t)f * g.plane_bytes;
+    if (blockIdx.x == gridDim.x - 1) {
+        const int rb = blockIdx.y * 4 * L0_RPT;
+        for (int i = threadIdx.y * 64 + threadIdx.x; i < 4 * L0_RPT * nb; i += 256) {
+            const int rr = i / nb;
+            int c16 = i - rr * nb;
+            if (c16 >= g_lo) c16 += g_hi - g_lo;
+            if (rb + rr < g.rows) level0_edge_group(src + (size_t)f * frame_stride, row_stride, D, g, rb + rr, c16);
+        }
+        return;
+    }
     const int c16 = g_lo + blockIdx.x * 64 + threadIdx.x;
     const int r0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * L0_RPT;
-    const int f = blockIdx.z;
     if (c16 >= g_hi || r0 >= g.rows) return;
     const uint8_t* S = src + (size_t)f * frame_stride + (c16 * 16 - ORB_OX);
-    uint8_t* D = pyr + g.pyr_off + (size_t)f * g.plane_bytes;
-    uint4 v[L0_RPT];
+    typedef unsigned int nv4 __attribute__((ext_vector_type(4)));
+    nv4 v[L0_RPT];
 #pragma unroll
     for (int k = 0; k < L0_RPT; k++) {                                  // all loads first: a wave is short
         int sy = min(r0 + k, g.rows - 1) - ORB_OY;
         sy = sy < 0 ? -sy : (sy >= g.h ? 2 * (g.h - 1) - sy : sy);     // the border is narrower than the image
-        v[k] = *reinterpret_cast<const uint4*>(S + (size_t)sy * row_stride);
+        v[k] = __builtin_nontemporal_load(reinterpret_cast<const nv4*>(S + (size_t)sy * row_stride));   // read once
     }
 #pragma unroll
     for (int k = 0; k < L0_RPT; k++)
-        if (r0 + k < g.rows) reinterpret_cast<uint4*>(D + (size_t)(r0 + k) * g.pitch)[c16] = v[k];
+        if (r0 + k < g.rows) reinterpret_cast<nv4*>(D + (size_t)(r0 + k) * g.pitch)[c16] = v[k];
 }
 
 __global__ __launch_bounds__(256) void k_level0_edges(const uint8_t* __restrict__ src, size_t row_stride,
@@ -58,17 +86,7 @@ __global__ __launch_bounds__(256) void k_level0_edges(const uint8_t* __restrict_
     if (r >= g.rows) return;
     int c16 = i - r * nb;
     if (c16 >= skip_lo) c16 += skip_hi - skip_lo;
-    const uint8_t* S = src + (size_t)f * frame_stride + (size_t)reflect101(r - ORB_OY, g.h) * row_stride;
-    const int x0 = c16 * 16 - ORB_OX;
-    uint32_t o[4];
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-        o[d] = 0;
-#pragma unroll
-        for (int b = 0; b < 4; b++) o[d] |= (uint32_t)S[reflect101(x0 + 4 * d + b, g.w)] << (8 * b);
-    }
-    uint8_t* D = pyr + g.pyr_off + (size_t)f * g.plane_bytes + (size_t)r * g.pitch;
-    reinterpret_cast<uint4*>(D)[c16] = make_uint4(o[0], o[1], o[2], o[3]);
+    level0_edge_group(src + (size_t)f * frame_stride, row_stride, pyr + g.pyr_off + (size_t)f * g.plane_bytes, g, r, c16);
 }
 
 // Level 0 from an interleaved 3- or 4-channel 8-bit image: the cvtColor(..., CV_RGB2GRAY / CV_BGR2GRAY /
