@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step")
     ap.add_argument("--max-batch", type=int, default=0, help="frames per internal pass (0 = library default)")
     ap.add_argument("--workload", default="C4_1080p_2000f", choices=sorted(WORKLOADS))
     ap.add_argument("--kind", default="blocks", choices=["blocks", "noise", "lowc"])
@@ -267,7 +267,10 @@ def main():
         lanes = max(1, min(int(os.environ.get("ORBHIP_LANES", "1")), 4))
         passes = max(timing["k_quadtree"][1] // (2 if args.stereo else 1), 1)   # one quadtree launch per pass and side
         frames_per_launch = B * args.steps / passes
-        traffic, traffic_src = profiled_traffic(kname, frames_per_launch)
+        # the committed counter summaries were collected on the default workload: they say nothing about another one
+        profiled = (args.workload == "C4_1080p_2000f" and args.kind == "blocks" and not args.stereo and not args.rectify
+                    and not args.color)
+        traffic, traffic_src = profiled_traffic(kname, frames_per_launch) if profiled else (None, None)
         copy_gbs = device_copy_gbs(torch, device)
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -281,7 +284,7 @@ def main():
                     "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in timing.items()}}
         # the limit that actually binds the dominant kernel: vector-ALU issue. A wave64 instruction
         # holds one of the 1024 SIMDs for 4 cycles; the rate below is at the 2.4 GHz peak clock.
-        valu, valu_src = profiled_valu(kname, frames_per_launch)
+        valu, valu_src = profiled_valu(kname, frames_per_launch) if profiled else (None, None)
         if valu:
             peak_rate = 256 * 4 / 4.0 * 2.4e9
             roofline["valu"] = {"wave_insts_per_launch": valu, "source": valu_src, "achieved_insts_per_s": round(valu / k_avg_s, 1),

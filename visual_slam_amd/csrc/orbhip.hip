@@ -478,7 +478,7 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || p->device < 0 || p->device >= ndev) return ORBHIP_ERR_NO_DEVICE;
     orbhip_extractor* e = new orbhip_extractor;
     e->prm = *p;
-    if (e->prm.max_batch < 1) e->prm.max_batch = 256;
+    if (e->prm.max_batch < 1) e->prm.max_batch = 512;
     e->device = p->device;
     const int nl = p->nlevels;
     // src/ORBextractor.cc:412-431 (scaleFactor is a double member initialised from the float argument)
@@ -580,7 +580,11 @@ static int extract_device_impl(orbhip_extractor* e, const uint8_t* d_imgs, int n
     // pyramid planes, FAST output segments, quadtree keys) under ~24 GB
     const double ws_per_frame = 20.0 * (double)width * (double)height;
     const int ws_limit = std::max(1, (int)(24e9 / ws_per_frame));
-    const int budget = std::max(1, std::min(e->prm.max_batch, ws_limit));   // frames in flight
+    // the descriptor kernel's one-dimensional grid (8 * groups of 4 keypoints * frames / 8 workgroups) finds
+    // its frame with a 32-bit multiply-high division that is exact while grid * 8 * groups < 2^32
+    const unsigned long long groups = ((unsigned long long)orbhip_max_keypoints(e) + 3) / 4;
+    const int grid_limit = (int)std::min<unsigned long long>(1u << 20, 8ull * (((1ull << 26) - 1) / (groups * groups)));
+    const int budget = std::max(1, std::min(std::min(e->prm.max_batch, ws_limit), std::max(grid_limit, 8)));   // frames in flight
     // Large batches run as passes of half the budget, alternating between two workspaces on two
     // internal streams that fork from and join back into the caller's stream. (Per-kernel timing
     // then measures every kernel as it runs, next to the other pass's kernels.)
