@@ -55,44 +55,41 @@ __device__ __forceinline__ v2s pick2(uint32_t hi, uint32_t lo) {
 }
 
 // Exact corner score of one pixel from its centre value and the 16 ring values (cv::FAST order).
+// With d = v - p: max over arcs of min(d) = v - min over arcs of max(p), and min over arcs of max(d) =
+// v - max over arcs of min(p), so the arcs are reduced on the ring values themselves and the centre
+// enters once at the end.
 __device__ __forceinline__ int fast_score16(int v, const int (&p)[16]) {
-    int d[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = v - p[k];
-    int lo2[8], hi2[8];   // min/max of d[i], d[i+1] for odd i = 2j+1
+    int lo2[8], hi2[8];   // min/max of p[i], p[i+1] for odd i = 2j+1
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        lo2[j] = min(d[(2 * j + 1) & 15], d[(2 * j + 2) & 15]);
-        hi2[j] = max(d[(2 * j + 1) & 15], d[(2 * j + 2) & 15]);
+        lo2[j] = min(p[(2 * j + 1) & 15], p[(2 * j + 2) & 15]);
+        hi2[j] = max(p[(2 * j + 1) & 15], p[(2 * j + 2) & 15]);
     }
-    int lo4[8], hi4[8];   // over d[i..i+3]
+    int lo4[8], hi4[8];   // over p[i..i+3]
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         lo4[j] = min(lo2[j], lo2[(j + 1) & 7]);
         hi4[j] = max(hi2[j], hi2[(j + 1) & 7]);
     }
-    int a0 = -256, b0 = 256;
+    int amin = 512, bmax = -512;   // min over arcs of the arc's brightest pixel, max over arcs of its darkest
 #pragma unroll
-    for (int j = 0; j < 8; j++) {   // arcs [k..k+8] and [k+1..k+9], k = 2j, share d[k+1..k+8]
+    for (int j = 0; j < 8; j++) {   // arcs [k..k+8] and [k+1..k+9], k = 2j, share p[k+1..k+8]
         const int k = 2 * j;
         const int lo8 = min(lo4[j], lo4[(j + 2) & 7]);
         const int hi8 = max(hi4[j], hi4[(j + 2) & 7]);
-        a0 = max(a0, min(lo8, max(d[k], d[(k + 9) & 15])));
-        b0 = min(b0, max(hi8, min(d[k], d[(k + 9) & 15])));
+        amin = min(amin, max(hi8, min(p[k], p[(k + 9) & 15])));
+        bmax = max(bmax, min(lo8, max(p[k], p[(k + 9) & 15])));
     }
-    return max(a0, -b0) - 1;
+    return max(v - amin, bmax - v) - 1;
 }
 
 // The same for two pixels at once: every value is a pair of 16-bit halves (packed min / max / sub).
 __device__ __forceinline__ v2s fast_score16_pk(v2s v, const v2s (&p)[16]) {
-    v2s d[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = v - p[k];
     v2s lo2[8], hi2[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        lo2[j] = pmin(d[(2 * j + 1) & 15], d[(2 * j + 2) & 15]);
-        hi2[j] = pmax(d[(2 * j + 1) & 15], d[(2 * j + 2) & 15]);
+        lo2[j] = pmin(p[(2 * j + 1) & 15], p[(2 * j + 2) & 15]);
+        hi2[j] = pmax(p[(2 * j + 1) & 15], p[(2 * j + 2) & 15]);
     }
     v2s lo4[8], hi4[8];
 #pragma unroll
@@ -100,17 +97,17 @@ __device__ __forceinline__ v2s fast_score16_pk(v2s v, const v2s (&p)[16]) {
         lo4[j] = pmin(lo2[j], lo2[(j + 1) & 7]);
         hi4[j] = pmax(hi2[j], hi2[(j + 1) & 7]);
     }
-    v2s a0 = {-256, -256}, b0 = {256, 256};
+    v2s amin = {512, 512}, bmax = {-512, -512};
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int k = 2 * j;
         const v2s lo8 = pmin(lo4[j], lo4[(j + 2) & 7]);
         const v2s hi8 = pmax(hi4[j], hi4[(j + 2) & 7]);
-        a0 = pmax(a0, pmin(lo8, pmax(d[k], d[(k + 9) & 15])));
-        b0 = pmin(b0, pmax(hi8, pmin(d[k], d[(k + 9) & 15])));
+        amin = pmin(amin, pmax(hi8, pmin(p[k], p[(k + 9) & 15])));
+        bmax = pmax(bmax, pmin(lo8, pmax(p[k], p[(k + 9) & 15])));
     }
-    const v2s one = {1, 1}, zero = {0, 0};
-    return pmax(a0, zero - b0) - one;
+    const v2s one = {1, 1};
+    return pmax(v - amin, bmax - v) - one;
 }
 
 #define FT_COLS 248        // output columns per tile (62 lanes x 4; lanes 0 and 63 are halo)
