@@ -276,6 +276,31 @@ int orbhip_search_by_projection(orbhip_extractor* e, const orbhip_keypoint* kp_l
  * Host only. */
 int orbhip_projection_level_mode(const float* Tcw_cur, const float* Tcw_last, float mb, int mono);
 
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound,
+ * const float th, const int ORBdist) (src/ORBmatcher.cc:1447-1564, relocalisation, src/Tracking.cc
+ * Tracking::Relocalization) on plain arrays, laid out like orbhip_search_by_projection_batch_device.
+ * Per key-frame keypoint i: d_kp_kf = pKF->mvKeysUn (the angle is read), d_world_kf = GetWorldPos()
+ * of GetMapPointMatches()[i], d_dist_range_kf = {mfMinDistance, mfMaxDistance} of that point,
+ * d_flags_kf bit 0 = "the point exists, is not bad and is not in sAlreadyFound", d_desc_kf =
+ * GetDescriptor(). Per current keypoint: mvKeysUn, descriptor, d_occupied_cur = 1 where
+ * CurrentFrame.mvpMapPoints[i2] is not NULL on entry (NULL: none). d_Tcw: 12 floats per frame.
+ * prm: camera, bounds, th, check_orientation (mbf is not read). d_match_cur[i2] = index of the
+ * key-frame keypoint whose point was assigned to current keypoint i2 by this call, else -1. */
+int orbhip_search_by_projection_keyframe_batch_device(orbhip_extractor* e, int nframes, int cap,
+                                                      const orbhip_keypoint* d_kp_kf, const float* d_world_kf,
+                                                      const float* d_dist_range_kf, const uint8_t* d_flags_kf,
+                                                      const uint8_t* d_desc_kf, const int* d_cnt_kf,
+                                                      const orbhip_keypoint* d_kp_cur, const uint8_t* d_desc_cur,
+                                                      const uint8_t* d_occupied_cur, const int* d_cnt_cur, const float* d_Tcw,
+                                                      const orbhip_projection_params* prm, int orb_dist,
+                                                      int* d_match_cur, int* d_nmatches, void* stream);
+/* The same for one frame / key frame with host arrays; waits for the result. */
+int orbhip_search_by_projection_keyframe(orbhip_extractor* e, const orbhip_keypoint* kp_kf, const float* world_kf,
+                                         const float* dist_range_kf, const uint8_t* flags_kf, const uint8_t* desc_kf, int n1,
+                                         const orbhip_keypoint* kp_cur, const uint8_t* desc_cur, const uint8_t* occupied_cur, int n2,
+                                         const float* Tcw, const orbhip_projection_params* prm, int orb_dist,
+                                         int* match_cur, int* nmatches);
+
 /* ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, const float th)
  * (src/ORBmatcher.cc:46-127, called by Tracking::SearchLocalPoints) on plain arrays.
  * A map point is described by what that function reads from it: the fields Frame::isInFrustum

@@ -1254,6 +1254,152 @@ int orbo_search_by_projection(const orbo_keypoint* k_last, const float* world_la
     return nmatches;
 }
 
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound,
+ * const float th, const int ORBdist) (src/ORBmatcher.cc:1447-1564, relocalisation) on plain arrays.
+ * Key frame, n1 keypoints: k_kf = pKF->mvKeysUn (angle), world_kf = GetWorldPos() of
+ * GetMapPointMatches()[i], dist_range_kf = {mfMinDistance, mfMaxDistance} pairs, flags_kf bit 0 = "the
+ * point exists, is not bad and is not in sAlreadyFound", desc_kf = GetDescriptor(). Current frame, n2
+ * keypoints: k_cur = mvKeysUn, desc_cur, occupied_cur[i2] = "mvpMapPoints[i2] is not NULL on entry"
+ * (NULL: none). scale_factor = mfScaleFactor, nlevels = mnScaleLevels. match_cur[i2] = index of the
+ * key-frame keypoint whose point this call assigned to i2, else -1. Returns nmatches.
+ * Ow = -Rcw.t() * tcw goes through the general CV_32F product (accumulated in double, stored as
+ * float), Rcw * x3Dw + tcw through the small-matrix one, cv::norm of three floats in double. */
+int orbo_search_by_projection_keyframe(const orbo_keypoint* k_kf, const float* world_kf, const float* dist_range_kf,
+                                       const uint8_t* flags_kf, const uint8_t* desc_kf, int n1, const orbo_keypoint* k_cur,
+                                       const uint8_t* desc_cur, const uint8_t* occupied_cur, int n2, const float* Tcw,
+                                       const float* cam, const float* bounds, const float* scale_factors, float scale_factor,
+                                       int nlevels, float th, int ORBdist, int mbCheckOrientation, int* match_cur) {
+    const int COLS = 64, ROWS = 48, HISTO_LENGTH = 30;
+    const float mnMinX = bounds[0], mnMaxX = bounds[1], mnMinY = bounds[2], mnMaxY = bounds[3];
+    const float wInv = static_cast<float>(COLS) / (mnMaxX - mnMinX);
+    const float hInv = static_cast<float>(ROWS) / (mnMaxY - mnMinY);
+    const float fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3];
+    const float mfLogScaleFactor = std::log(scale_factor);
+    std::vector<std::vector<size_t>> mGrid((size_t)COLS * ROWS);
+    for (int i = 0; i < n2; i++) {
+        const int posX = (int)std::round((k_cur[i].x - mnMinX) * wInv);
+        const int posY = (int)std::round((k_cur[i].y - mnMinY) * hInv);
+        if (posX < 0 || posX >= COLS || posY < 0 || posY >= ROWS) continue;
+        mGrid[(size_t)posX * ROWS + posY].push_back((size_t)i);
+    }
+    auto GetFeaturesInArea = [&](float x, float y, float r, int minLevel, int maxLevel) {   /* src/Frame.cc:351-401 */
+        std::vector<size_t> vIndices;
+        const int nMinCellX = std::max(0, (int)std::floor((x - mnMinX - r) * wInv));
+        if (nMinCellX >= COLS) return vIndices;
+        const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((x - mnMinX + r) * wInv));
+        if (nMaxCellX < 0) return vIndices;
+        const int nMinCellY = std::max(0, (int)std::floor((y - mnMinY - r) * hInv));
+        if (nMinCellY >= ROWS) return vIndices;
+        const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((y - mnMinY + r) * hInv));
+        if (nMaxCellY < 0) return vIndices;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                const std::vector<size_t>& vCell = mGrid[(size_t)ix * ROWS + iy];
+                for (size_t j = 0; j < vCell.size(); j++) {
+                    const orbo_keypoint& kpUn = k_cur[vCell[j]];
+                    if (bCheckLevels) {
+                        if (kpUn.octave < minLevel) continue;
+                        if (maxLevel >= 0 && kpUn.octave > maxLevel) continue;
+                    }
+                    const float distx = kpUn.x - x, disty = kpUn.y - y;
+                    if (std::fabs(distx) < r && std::fabs(disty) < r) vIndices.push_back(vCell[j]);
+                }
+            }
+        return vIndices;
+    };
+    auto DescriptorDistance = [](const uint8_t* a, const uint8_t* b) {   /* src/ORBmatcher.cc:1611-1627 */
+        int dist = 0;
+        for (int i = 0; i < 8; i++) {
+            uint32_t pa, pb;
+            std::memcpy(&pa, a + 4 * i, 4); std::memcpy(&pb, b + 4 * i, 4);
+            unsigned int v = pa ^ pb;
+            v = v - ((v >> 1) & 0x55555555);
+            v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+            dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+        }
+        return dist;
+    };
+    int nmatches = 0;
+    float Ow[3];
+    for (int r = 0; r < 3; r++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)Tcw[3 * k + r] * (double)Tcw[9 + k];
+        Ow[r] = (float)(-s);
+    }
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<char> holds((size_t)n2);                       /* CurrentFrame.mvpMapPoints[i2] != NULL */
+    for (int i = 0; i < n2; i++) { holds[i] = occupied_cur && occupied_cur[i]; match_cur[i] = -1; }
+    for (int i = 0; i < n1; i++) {
+        if (!(flags_kf[i] & 1)) continue;
+        const float* X = world_kf + 3 * (size_t)i;
+        float x3Dc[3];
+        for (int r = 0; r < 3; r++) {
+            const float t = Tcw[3 * r] * X[0] + Tcw[3 * r + 1] * X[1] + Tcw[3 * r + 2] * X[2];
+            x3Dc[r] = (float)((double)t * 1.0 + (double)Tcw[9 + r] * 1.0);
+        }
+        const float xc = x3Dc[0], yc = x3Dc[1];
+        const float invzc = (float)(1.0 / x3Dc[2]);
+        const float u = fx * xc * invzc + cx;
+        const float v = fy * yc * invzc + cy;
+        if (!(u == u) || !(v == v)) continue;                  /* undefined in the reference */
+        if (u < mnMinX || u > mnMaxX) continue;
+        if (v < mnMinY || v > mnMaxY) continue;
+        const float PO[3] = {X[0] - Ow[0], X[1] - Ow[1], X[2] - Ow[2]};
+        double nrm = 0;
+        for (int k = 0; k < 3; k++) { const double e = PO[k]; nrm += e * e; }
+        const float dist3D = (float)std::sqrt(nrm);
+        const float maxDistance = 1.2f * dist_range_kf[2 * i + 1];
+        const float minDistance = 0.8f * dist_range_kf[2 * i];
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const float ratio = dist_range_kf[2 * i + 1] / dist3D;  /* MapPoint::PredictScale */
+        const float c = std::ceil(std::log(ratio) / mfLogScaleFactor);
+        int nPredictedLevel = (c >= -2147483648.0f && c < 2147483648.0f) ? (int)c : (-2147483647 - 1);
+        if (nPredictedLevel < 0) nPredictedLevel = 0;
+        else if (nPredictedLevel >= nlevels) nPredictedLevel = nlevels - 1;
+        const float radius = th * scale_factors[nPredictedLevel];
+        const std::vector<size_t> vIndices2 = GetFeaturesInArea(u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* dMP = desc_kf + 32 * (size_t)i;
+        int bestDist = 256, bestIdx2 = -1;
+        for (size_t i2 : vIndices2) {
+            if (holds[i2]) continue;
+            const int dist = DescriptorDistance(dMP, desc_cur + 32 * i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+        }
+        if (bestDist <= ORBdist) {
+            holds[bestIdx2] = 1;
+            match_cur[bestIdx2] = i;
+            nmatches++;
+            if (mbCheckOrientation) {
+                float rot = k_kf[i].angle - k_cur[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        int max1 = 0, max2 = 0, max3 = 0;                      /* ComputeThreeMaxima (src/ORBmatcher.cc:1566-1607) */
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int sz = (int)rotHist[i].size();
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx2 : rotHist[i]) { match_cur[idx2] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 /* ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, const float th)
  * (src/ORBmatcher.cc:46-127; the matcher of Tracking::SearchLocalPoints) with RadiusByViewingCos
  * (:129-135) on plain arrays. mp[i] holds what the function reads from vpMapPoints[i]: mTrackProjX,

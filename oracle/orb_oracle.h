@@ -119,6 +119,12 @@ int orbo_search_for_initialization(const orbo_keypoint* k1, const uint8_t* d1, i
                                    float* prev_matched, int windowSize, float mfNNratio, int mbCheckOrientation,
                                    int* matches12);
 
+/* ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1447-1564). */
+int orbo_search_by_projection_keyframe(const orbo_keypoint* k_kf, const float* world_kf, const float* dist_range_kf,
+                                       const uint8_t* flags_kf, const uint8_t* desc_kf, int n1, const orbo_keypoint* k_cur,
+                                       const uint8_t* desc_cur, const uint8_t* occupied_cur, int n2, const float* Tcw,
+                                       const float* cam, const float* bounds, const float* scale_factors, float scale_factor,
+                                       int nlevels, float th, int ORBdist, int mbCheckOrientation, int* match_cur);
 /* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:46-127). */
 typedef struct orbo_track_point { float proj_x, proj_y, proj_xr, view_cos; int32_t level, flags; } orbo_track_point;
 int orbo_search_map_points(const orbo_track_point* mp, const uint8_t* desc_mp, int n1, const orbo_keypoint* k,

@@ -87,6 +87,8 @@ def lib():
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
         L.orbo_is_in_frustum.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_int,
                                          C.c_float, C.c_void_p]
+        L.orbo_search_by_projection_keyframe.argtypes = [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4 + \
+            [C.c_float, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
         L.orbo_libm_logf.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orbo_libm_sincos.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orbo_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
@@ -391,3 +393,23 @@ def libm_logf(first_bits, count, stride=1):
     out = np.empty(count, np.float32)
     lib().orbo_libm_logf(int(first_bits), int(count), int(stride), _ptr(out))
     return out
+
+
+def search_by_projection_keyframe(kp_kf, world_kf, dist_range_kf, flags_kf, desc_kf, kp_cur, desc_cur, occupied_cur, Tcw, cam4, bounds,
+                                  scale_factors, scale_factor, th, orb_dist, check_orientation=True):
+    """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist): returns (match_cur, nmatches)."""
+    kp_kf = np.ascontiguousarray(kp_kf, KP_DTYPE); kp_cur = np.ascontiguousarray(kp_cur, KP_DTYPE)
+    world = np.ascontiguousarray(world_kf, np.float32).reshape(-1, 3)
+    rng_ = np.ascontiguousarray(dist_range_kf, np.float32).reshape(-1, 2)
+    flags = np.ascontiguousarray(flags_kf, np.uint8)
+    d1 = np.ascontiguousarray(desc_kf, np.uint8); d2 = np.ascontiguousarray(desc_cur, np.uint8)
+    oc = None if occupied_cur is None else np.ascontiguousarray(occupied_cur, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    m = np.full(max(len(kp_cur), 1), -1, np.int32)
+    n = lib().orbo_search_by_projection_keyframe(_ptr(kp_kf), _ptr(world), _ptr(rng_), _ptr(flags), _ptr(d1), len(kp_kf), _ptr(kp_cur),
+                                                 _ptr(d2), None if oc is None else _ptr(oc), len(kp_cur),
+                                                 _ptr(np.ascontiguousarray(Tcw, np.float32).reshape(12)),
+                                                 _ptr(np.ascontiguousarray(cam4, np.float32)), _ptr(np.ascontiguousarray(bounds, np.float32)),
+                                                 _ptr(sf), float(np.float32(scale_factor)), len(sf), float(th), int(orb_dist),
+                                                 int(bool(check_orientation)), _ptr(m))
+    return m[:len(kp_cur)], n

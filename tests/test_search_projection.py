@@ -144,3 +144,69 @@ def test_hip_search_by_projection_contested_keypoints():
     assert gn == on and np.array_equal(gm, om)
     assert on > (om >= 0).sum()                                  # overwritten assignments still count, as in the reference
     assert orbhip.ProjectionLevelMode(s["Tcw"], np.concatenate([np.eye(3).ravel(), [0, 0, 0]]), 0.5, False) == 0
+
+
+# ---- the relocalisation variant: SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist)
+# (reference src/ORBmatcher.cc:1447-1564)
+
+def keyframe_scenario(w, h, index, dx, dy, cam, seed=17, prm=(2000, 1.2, 8, 20, 7)):
+    s = scenario(w, h, index, dx, dy, cam, prm=prm)
+    rng = np.random.default_rng(seed)
+    n1 = len(s["u1"])
+    # the depth at which the point was created: mostly near the current one, sometimes far off (range test, other levels)
+    ref = Z * rng.choice([1.0, 1.0, 1.0, 1.3, 0.7, 4.0, 0.1], n1)
+    maxd = (ref * s["sf"][s["u1"]["octave"]]).astype(np.float32)              # MapPoint::UpdateNormalAndDepth
+    s["range"] = np.stack([maxd / s["sf"][-1], maxd], axis=1).astype(np.float32)
+    s["flags"] = (rng.random(n1) < 0.85).astype(np.uint8)
+    s["occupied"] = (rng.random(len(s["u2"])) < 0.3).astype(np.uint8)
+    return s
+
+
+def run_oracle_kf(s, th, orb_dist, ori, occupied=True):
+    from oracle import orb_oracle as O
+    return O.search_by_projection_keyframe(s["u1"], s["world"], s["range"], s["flags"], s["d1"], s["u2"], s["d2"],
+                                           s["occupied"] if occupied else None, s["Tcw"], s["cam4"], s["bounds"], s["sf"], 1.2, th,
+                                           orb_dist, ori)
+
+
+def test_oracle_keyframe_projection_properties():
+    s = keyframe_scenario(640, 480, 75, 8, -5, KITTI)
+    m, n = run_oracle_kf(s, 10, 100, True)
+    got = m >= 0
+    assert n == got.sum() and n > 200                          # every assignment occupies its keypoint: none is overwritten
+    assert not np.any(got & (s["occupied"] != 0))               # keypoints that held a point on entry stay as they were
+    assert np.all(s["flags"][m[got]] & 1)
+    # a point whose distance lies outside its scale-invariance range is never matched
+    d = np.linalg.norm(s["world"][m[got]] - (-s["Tcw"][9:12]), axis=1)      # R = I: Ow = -t
+    assert np.all((d >= 0.8 * s["range"][m[got], 0] * 0.999) & (d <= 1.2 * s["range"][m[got], 1] * 1.001))
+    # a tighter descriptor threshold only removes matches
+    m2, n2 = run_oracle_kf(s, 10, 40, True)
+    assert 0 < n2 < n
+    # without the occupancy on entry more keypoints are free
+    m3, n3 = run_oracle_kf(s, 10, 100, True, occupied=False)
+    assert n3 > n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cam,w,h,dx,dy,th,orb_dist,ori", [
+    (KITTI, 1241, 376, 9, 3, 10, 100, True),
+    (TUM1, 640, 480, -11, 8, 3, 64, True),
+    (KITTI, 752, 480, 14, -5, 10, 100, False),
+])
+def test_hip_keyframe_projection_matches_oracle(cam, w, h, dx, dy, th, orb_dist, ori):
+    from visual_slam_amd import orbhip
+    s = keyframe_scenario(w, h, 76, dx, dy, cam)
+    om, on = run_oracle_kf(s, th, orb_dist, ori)
+    ex = orbhip.ORBextractor(2000, 1.2, 8, 20, 7)
+    gm, gn = orbhip.SearchByProjectionKeyFrame(ex, s["u1"], s["world"], s["range"], s["flags"], s["d1"], s["u2"], s["d2"], s["occupied"],
+                                               s["Tcw"], s["cam4"], s["bounds"], th, orb_dist, ori)
+    assert on > 60 and gn == on
+    assert np.array_equal(gm, om)
+    # contested: every key-frame point twice, nothing occupied on entry
+    for k in ("u1", "world", "range", "flags", "d1"):
+        s[k] = np.concatenate([s[k], s[k]])
+    if len(s["u1"]) <= 2800:
+        om, on = run_oracle_kf(s, th, orb_dist, ori, occupied=False)
+        gm, gn = orbhip.SearchByProjectionKeyFrame(ex, s["u1"], s["world"], s["range"], s["flags"], s["d1"], s["u2"], s["d2"], None,
+                                                   s["Tcw"], s["cam4"], s["bounds"], th, orb_dist, ori)
+        assert gn == on and np.array_equal(gm, om)

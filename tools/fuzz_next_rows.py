@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random-parameter sweep of the device paths next to the extraction (rectification, the three
+"""Random-parameter sweep of the device paths next to the extraction (rectification, the
 matchers) against the oracle. One-off robustness tool: prints the failing draws, exit status 1 if any.
 
 Usage: python tools/fuzz_next_rows.py [--cases 60] [--seed 1]
@@ -97,6 +97,17 @@ def main():
         gm12, gp, gn2 = orbhip.SearchForInitialization(ex, u1, d1, u2, d2, bounds, prev, win, ratio, ori)
         if gn2 != on2 or not np.array_equal(gm12, om12) or not np.array_equal(gp.view(np.uint32), op.view(np.uint32)):
             bad += 1; print(tag, "INITIALIZATION MISMATCH", gn2, on2)
+        # the relocalisation variant of the projection matcher: distance ranges around the true depth, some far off
+        ref = Z * rng.choice([1.0, 1.0, 1.3, 0.7, 4.0, 0.1], len(u1))
+        maxd = (ref * sf[u1["octave"]]).astype(np.float32)
+        drange = np.stack([maxd / sf[-1], maxd], axis=1).astype(np.float32)
+        occ_kf = (rng.random(len(u2)) < rng.uniform(0, 0.5)).astype(np.uint8) if rng.random() < 0.7 else None
+        odist = int(rng.choice([40, 64, 100]))
+        om4, on4 = O.search_by_projection_keyframe(u1, world, drange, flags & 1, d1, u2, d2, occ_kf, Tcw, cam[:4], bounds, sf, prm[1], th,
+                                                   odist, ori)
+        gm4, gn4 = orbhip.SearchByProjectionKeyFrame(ex, u1, world, drange, flags & 1, d1, u2, d2, occ_kf, Tcw, cam[:4], bounds, th, odist, ori)
+        if gn4 != on4 or not np.array_equal(gm4, om4):
+            bad += 1; print(tag, "KEYFRAME PROJECTION MISMATCH", gn4, on4, int((gm4 != om4).sum()))
         # the local-map matcher: the first view's keypoints (several copies, shuffled) as map points
         copies = int(rng.integers(1, 4))
         src = np.tile(np.arange(len(u1)), copies); rng.shuffle(src)

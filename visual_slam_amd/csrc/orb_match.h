@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include "orb_device.h"
 #include "orb_grid.h"
+#include "orb_libm.h"
 
 #define MT_TH_LOW 50          // ORBmatcher::TH_LOW (src/ORBmatcher.cc:39)
 #define MT_HISTO 30           // ORBmatcher::HISTO_LENGTH (src/ORBmatcher.cc:40)
@@ -221,12 +222,28 @@ struct ProjArgs {
     int check_orientation;
 };
 
+// KEYFRAME: the variant of relocalisation, ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF,
+// sAlreadyFound, th, ORBdist) (reference src/ORBmatcher.cc:1447-1564). "Last frame" then reads "key frame";
+// what differs: no test of the depth's sign, the point's distance to the camera centre Ow = -Rcw^T tcw
+// must lie in its scale-invariance range and predicts the level (MapPoint::PredictScale) in place
+// of the keypoint's octave, levels [level - 1, level + 1] always, no mvuRight test, the acceptance
+// threshold is ORBdist, and a current keypoint that holds any map point is skipped: the ones that
+// hold one on entry (occupied2) and every one assigned here.
+struct KeyframeArgs {
+    const float2* dist_range1;    // per key-frame keypoint: mfMinDistance, mfMaxDistance of its map point
+    const uint8_t* occupied2;     // per current keypoint: CurrentFrame.mvpMapPoints[i2] != NULL on entry (may be NULL)
+    int orb_dist;
+    float log_scale_factor;
+    int nlevels;
+};
+
+template <bool KEYFRAME>
 __global__ __launch_bounds__(MP_THREADS) void k_search_proj(const GridKp* __restrict__ kp1, const float* __restrict__ world1,
                                                      const uint8_t* __restrict__ flags1, const uint8_t* __restrict__ desc1,
                                                      const int* __restrict__ cnt1, const GridKp* __restrict__ kp2,
                                                      const uint8_t* __restrict__ desc2, const float* __restrict__ uright2,
                                                      const int* __restrict__ cnt2, int cap, const float* __restrict__ Tcw,
-                                                     const int* __restrict__ level_mode, ProjArgs a, ScaleTab sf,
+                                                     const int* __restrict__ level_mode, ProjArgs a, ScaleTab sf, KeyframeArgs kf,
                                                      int* __restrict__ match2, int* __restrict__ nmatches_out) {
     extern __shared__ __align__(16) uint8_t mp_smem[];
     uint32_t* list1 = reinterpret_cast<uint32_t*>(mp_smem);                  // last: MP_LIST x (distance << 16 | current index), best first, occupancy ignored
@@ -269,8 +286,8 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_proj(const GridKp* __rest
         ur2[i] = uright2 ? uright2[o + i] : -1.0f;
         cell2[i] = (uint16_t)(cell < 0 ? 0xFFFF : cell);
         oct2[i] = (uint8_t)k.octave;
-        occ2[i] = 0;
-        m2[i] = -1;                                            // CurrentFrame.mvpMapPoints is all NULL on entry
+        occ2[i] = (uint8_t)(KEYFRAME && kf.occupied2 ? kf.occupied2[o + i] != 0 : 0);
+        m2[i] = -1;                                            // nothing assigned by this call yet
         if (cell >= 0) atomicAdd(&s_cur[cell], 1u);
     }
     // projections of the last frame's map points (src/ORBmatcher.cc:1343-1361)
@@ -289,11 +306,24 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_proj(const GridKp* __rest
             const float invzc = (float)(1.0 / (double)zc);
             const float u = a.fx * xc * invzc + a.cx;
             const float v = a.fy * yc * invzc + a.cy;
-            const bool ok = !(invzc < 0) && u == u && v == v && !(u < a.min_x || u > a.max_x) && !(v < a.min_y || v > a.max_y);
+            bool ok = (KEYFRAME || !(invzc < 0)) && u == u && v == v && !(u < a.min_x || u > a.max_x) && !(v < a.min_y || v > a.max_y);
+            int lvl = K1[i].octave & (ORB_MAX_LEVELS - 1);
+            if (KEYFRAME) {
+                // Ow = -Rcw^T tcw as the matrix expression computes it (accumulated in double, stored as float);
+                // PO = x3Dw - Ow in float, cv::norm in double (src/ORBmatcher.cc:1452,1480-1490)
+                const float ox = (float)(-((double)r00 * (double)t0 + (double)r10 * (double)t1 + (double)r20 * (double)t2));
+                const float oy = (float)(-((double)r01 * (double)t0 + (double)r11 * (double)t1 + (double)r21 * (double)t2));
+                const float oz = (float)(-((double)r02 * (double)t0 + (double)r12 * (double)t1 + (double)r22 * (double)t2));
+                const float px = X - ox, py = Y - oy, pz = Z - oz;
+                const float dist3 = (float)sqrt((double)px * (double)px + (double)py * (double)py + (double)pz * (double)pz);
+                const float2 range = kf.dist_range1[o + i];
+                ok = ok && !(dist3 < 0.8f * range.x || dist3 > 1.2f * range.y);
+                lvl = predict_scale(range.y, dist3, kf.log_scale_factor, kf.nlevels);
+            }
             if (ok) {
                 uv1[i] = make_float2(u, v);
                 ur1[i] = u - a.mbf * invzc;
-                st = (uint8_t)(1 | (fl & 2) | ((K1[i].octave & (ORB_MAX_LEVELS - 1)) << 2));
+                st = (uint8_t)(1 | (KEYFRAME ? 2 : (fl & 2)) | (lvl << 2));
             }
         }
         st1[i] = st;
@@ -346,14 +376,14 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_proj(const GridKp* __rest
                 if (o2 < lo || o2 > hi) continue;
                 const float2 q = pos2[i2];
                 if (!(fabsf(q.x - p.x) < r && fabsf(q.y - p.y) < r)) continue;
-                if (use_occ && occ2[i2]) continue;
+                if ((use_occ || KEYFRAME) && occ2[i2]) continue;   // (before the ordered walk occ2 holds the occupancy on entry)
                 const float u2 = ur2[i2];
-                if (u2 > 0 && fabsf(ur - u2) > r) continue;    // src/ORBmatcher.cc:1380-1385
+                if (!KEYFRAME && u2 > 0 && fabsf(ur - u2) > r) continue;    // src/ORBmatcher.cc:1380-1385
                 const uint4* d2p = reinterpret_cast<const uint4*>(desc2 + (o + i2) * 32);
                 const uint4 x = d2p[0], y = d2p[1];
                 const unsigned dist = __popc(x.x ^ da.x) + __popc(x.y ^ da.y) + __popc(x.z ^ da.z) + __popc(x.w ^ da.w) +
                                       __popc(y.x ^ db.x) + __popc(y.y ^ db.y) + __popc(y.z ^ db.z) + __popc(y.w ^ db.w);
-                if (dist > MP_TH_HIGH) continue;               // can never be accepted (src/ORBmatcher.cc:1396)
+                if ((int)dist > (KEYFRAME ? kf.orb_dist : MP_TH_HIGH)) continue;   // can never be accepted (src/ORBmatcher.cc:1396,1520)
                 const unsigned long long key = ((unsigned long long)dist << 40) | ((unsigned long long)cell << 20) | (unsigned)i2;
                 seen++;
                 if (key < b1) { b2 = b1; b1 = key; }

@@ -1191,7 +1191,7 @@ int orbhip_search_by_projection_batch_device(orbhip_extractor* e, int nframes, i
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     if (lds > 40 * 1024)
-        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_proj), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_proj<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProjArgs a;
     a.fx = prm->fx; a.fy = prm->fy; a.cx = prm->cx; a.cy = prm->cy; a.mbf = prm->mbf;
     a.min_x = prm->bounds[0]; a.max_x = prm->bounds[1]; a.min_y = prm->bounds[2]; a.max_y = prm->bounds[3];
@@ -1201,9 +1201,9 @@ int orbhip_search_by_projection_batch_device(orbhip_extractor* e, int nframes, i
     a.check_orientation = prm->check_orientation;
     ScaleTab sf;
     for (int l = 0; l < ORB_MAX_LEVELS; l++) sf.v[l] = e->sf[std::min(l, e->prm.nlevels - 1)];
-    hipLaunchKernelGGL(k_search_proj, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const GridKp*>(d_kp_last), d_world_last,
+    hipLaunchKernelGGL(k_search_proj<false>, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const GridKp*>(d_kp_last), d_world_last,
                        d_flags_last, d_desc_last, d_cnt_last, reinterpret_cast<const GridKp*>(d_kp_cur), d_desc_cur, d_uright_cur,
-                       d_cnt_cur, cap, d_Tcw, d_level_mode, a, sf, d_match_cur, d_nmatches);
+                       d_cnt_cur, cap, d_Tcw, d_level_mode, a, sf, KeyframeArgs{nullptr, nullptr, 0, 0.0f, 0}, d_match_cur, d_nmatches);
     HIP_TRY(e, hipGetLastError());
     return ORBHIP_OK;
 }
@@ -1254,6 +1254,98 @@ int orbhip_search_by_projection(orbhip_extractor* e, const orbhip_keypoint* kp_l
     if (uright_cur) HIP_TRY(e, hipMemcpy(d_u, uright_cur, (size_t)n2 * 4, hipMemcpyHostToDevice));
     int rc = orbhip_search_by_projection_batch_device(e, 1, cap, d_k1, d_w, d_f, d_d1, d_cnt, d_k2, d_d2, uright_cur ? d_u : nullptr,
                                                       d_cnt + 1, d_T, d_cnt + 3, prm, d_m, d_cnt + 2, nullptr);
+    if (rc) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(match_cur, d_m, (size_t)n2 * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(nmatches, d_cnt + 2, sizeof(int), hipMemcpyDeviceToHost));
+    return ORBHIP_OK;
+}
+
+int orbhip_search_by_projection_keyframe_batch_device(orbhip_extractor* e, int nframes, int cap,
+                                                      const orbhip_keypoint* d_kp_kf, const float* d_world_kf,
+                                                      const float* d_dist_range_kf, const uint8_t* d_flags_kf,
+                                                      const uint8_t* d_desc_kf, const int* d_cnt_kf,
+                                                      const orbhip_keypoint* d_kp_cur, const uint8_t* d_desc_cur,
+                                                      const uint8_t* d_occupied_cur, const int* d_cnt_cur, const float* d_Tcw,
+                                                      const orbhip_projection_params* prm, int orb_dist,
+                                                      int* d_match_cur, int* d_nmatches, void* stream) {
+    if (!e || nframes < 1 || cap < 1 || cap > 65534 || !d_kp_kf || !d_world_kf || !d_dist_range_kf || !d_flags_kf || !d_desc_kf ||
+        !d_cnt_kf || !d_kp_cur || !d_desc_cur || !d_cnt_cur || !d_Tcw || !prm || !d_match_cur || !d_nmatches || orb_dist < 0 ||
+        !(prm->bounds[1] > prm->bounds[0]) || !(prm->bounds[3] > prm->bounds[2]))
+        return ORBHIP_ERR_ARG;
+    const size_t lds = (size_t)MP_LDS_PER_KP * cap + 16;
+    if (lds > 160 * 1024 - 20 * 1024) { e->err = "too many keypoints per frame for the on-chip matcher state"; return ORBHIP_ERR_CAPACITY; }
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    if (lds > 40 * 1024)
+        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_proj<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProjArgs a;
+    a.fx = prm->fx; a.fy = prm->fy; a.cx = prm->cx; a.cy = prm->cy; a.mbf = prm->mbf;
+    a.min_x = prm->bounds[0]; a.max_x = prm->bounds[1]; a.min_y = prm->bounds[2]; a.max_y = prm->bounds[3];
+    a.inv_w = static_cast<float>(GRID_COLS) / (prm->bounds[1] - prm->bounds[0]);   // src/Frame.cc:128-129
+    a.inv_h = static_cast<float>(GRID_ROWS) / (prm->bounds[3] - prm->bounds[2]);
+    a.th = prm->th;
+    a.check_orientation = prm->check_orientation;
+    ScaleTab sf;
+    for (int l = 0; l < ORB_MAX_LEVELS; l++) sf.v[l] = e->sf[std::min(l, e->prm.nlevels - 1)];
+    const KeyframeArgs kf{reinterpret_cast<const float2*>(d_dist_range_kf), d_occupied_cur, orb_dist,
+                          std::log((float)e->scale_factor_d), e->prm.nlevels};
+    hipLaunchKernelGGL(k_search_proj<true>, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const GridKp*>(d_kp_kf), d_world_kf,
+                       d_flags_kf, d_desc_kf, d_cnt_kf, reinterpret_cast<const GridKp*>(d_kp_cur), d_desc_cur, (const float*)nullptr,
+                       d_cnt_cur, cap, d_Tcw, (const int*)nullptr, a, sf, kf, d_match_cur, d_nmatches);
+    HIP_TRY(e, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_search_by_projection_keyframe(orbhip_extractor* e, const orbhip_keypoint* kp_kf, const float* world_kf,
+                                         const float* dist_range_kf, const uint8_t* flags_kf, const uint8_t* desc_kf, int n1,
+                                         const orbhip_keypoint* kp_cur, const uint8_t* desc_cur, const uint8_t* occupied_cur, int n2,
+                                         const float* Tcw, const orbhip_projection_params* prm, int orb_dist,
+                                         int* match_cur, int* nmatches) {
+    if (!e || n1 < 0 || n2 < 0 || !Tcw || !prm || !nmatches) return ORBHIP_ERR_ARG;
+    if (n2 > 0 && !match_cur) return ORBHIP_ERR_ARG;
+    for (int i = 0; i < n2; i++) match_cur[i] = -1;
+    if (n1 == 0 || n2 == 0) { *nmatches = 0; return ORBHIP_OK; }
+    if (!kp_kf || !world_kf || !dist_range_kf || !flags_kf || !desc_kf || !kp_cur || !desc_cur) return ORBHIP_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    const int cap = std::max(n1, n2);
+    auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
+    const size_t kpb = up((size_t)cap * sizeof(orbhip_keypoint)), db = up((size_t)cap * 32), wb = up((size_t)cap * 12);
+    const size_t rb = up((size_t)cap * 8), fb = up((size_t)cap), mb = up((size_t)cap * 4);
+    const size_t need = 128 + 2 * kpb + 2 * db + wb + rb + 2 * fb + mb;
+    if (need > e->d_st_tmp_bytes) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        dfree(e->d_st_tmp);
+        HIP_TRY(e, hipMalloc(&e->d_st_tmp, need));
+        e->d_st_tmp_bytes = need;
+    }
+    uint8_t* p = e->d_st_tmp;
+    int* d_cnt = reinterpret_cast<int*>(p);                     // [0] n1, [1] n2, [2] matches
+    float* d_T = reinterpret_cast<float*>(p + 64); p += 128;
+    orbhip_keypoint* d_k1 = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
+    orbhip_keypoint* d_k2 = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
+    uint8_t* d_d1 = p; p += db;
+    uint8_t* d_d2 = p; p += db;
+    float* d_w = reinterpret_cast<float*>(p); p += wb;
+    float* d_r = reinterpret_cast<float*>(p); p += rb;
+    uint8_t* d_f = p; p += fb;
+    uint8_t* d_o = p; p += fb;
+    int* d_m = reinterpret_cast<int*>(p);
+    const int cnt[3] = {n1, n2, 0};
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(d_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_T, Tcw, 12 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_k1, kp_kf, (size_t)n1 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_d1, desc_kf, (size_t)n1 * 32, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_w, world_kf, (size_t)n1 * 12, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_r, dist_range_kf, (size_t)n1 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_f, flags_kf, (size_t)n1, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_k2, kp_cur, (size_t)n2 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_d2, desc_cur, (size_t)n2 * 32, hipMemcpyHostToDevice));
+    if (occupied_cur) HIP_TRY(e, hipMemcpy(d_o, occupied_cur, (size_t)n2, hipMemcpyHostToDevice));
+    int rc = orbhip_search_by_projection_keyframe_batch_device(e, 1, cap, d_k1, d_w, d_r, d_f, d_d1, d_cnt, d_k2, d_d2,
+                                                               occupied_cur ? d_o : nullptr, d_cnt + 1, d_T, prm, orb_dist, d_m,
+                                                               d_cnt + 2, nullptr);
     if (rc) return rc;
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     HIP_TRY(e, hipMemcpy(match_cur, d_m, (size_t)n2 * sizeof(int), hipMemcpyDeviceToHost));

@@ -38,6 +38,7 @@ EXPORTS = [
     "orbhip_set_rectification", "orbhip_debug_sincos",
     "orbhip_search_map_points", "orbhip_search_map_points_batch_device",
     "orbhip_is_in_frustum", "orbhip_is_in_frustum_batch_device", "orbhip_debug_logf",
+    "orbhip_search_by_projection_keyframe", "orbhip_search_by_projection_keyframe_batch_device",
 ]
 
 
@@ -105,6 +106,8 @@ def lib():
         L.orbhip_projection_level_mode.argtypes = [vp, vp, C.c_float, C.c_int]
         L.orbhip_set_rectification.argtypes = [vp, vp, vp, C.c_int, C.c_int]
         L.orbhip_debug_sincos.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]
+        L.orbhip_search_by_projection_keyframe.argtypes = [vp] * 6 + [C.c_int] + [vp] * 3 + [C.c_int, vp, vp, C.c_int, vp, ip]
+        L.orbhip_search_by_projection_keyframe_batch_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 12 + [C.c_int, vp, vp, vp]
         L.orbhip_debug_logf.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
         L.orbhip_is_in_frustum.argtypes = [vp, vp, C.c_int, vp, vp, C.c_float, vp, ip]
         L.orbhip_is_in_frustum_batch_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_float, vp, vp, vp]
@@ -200,6 +203,26 @@ def SearchByProjection(ex, kp_last, world_last, flags_last, desc_last, kp_cur, d
     ex._check(lib().orbhip_search_by_projection(ex._h, _ptr(kp_last), _ptr(world), _ptr(flags), _ptr(d1), len(kp_last),
                                                 _ptr(kp_cur), _ptr(d2), None if ur is None else _ptr(ur), len(kp_cur),
                                                 _ptr(T), int(level_mode), C.byref(prm), _ptr(m), C.byref(n)))
+    return m[:len(kp_cur)], n.value
+
+
+def SearchByProjectionKeyFrame(ex, kp_kf, world_kf, dist_range_kf, flags_kf, desc_kf, kp_cur, desc_cur, occupied_cur, Tcw, cam4,
+                               bounds, th, orb_dist, check_orientation=True):
+    """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (reference
+    src/ORBmatcher.cc:1447-1564, relocalisation) on the device. Returns (match_cur, nmatches)."""
+    kp_kf = np.ascontiguousarray(kp_kf, KP_DTYPE); kp_cur = np.ascontiguousarray(kp_cur, KP_DTYPE)
+    world = np.ascontiguousarray(world_kf, np.float32).reshape(-1, 3)
+    rng_ = np.ascontiguousarray(dist_range_kf, np.float32).reshape(-1, 2)
+    flags = np.ascontiguousarray(flags_kf, np.uint8)
+    d1 = np.ascontiguousarray(desc_kf, np.uint8); d2 = np.ascontiguousarray(desc_cur, np.uint8)
+    oc = None if occupied_cur is None else np.ascontiguousarray(occupied_cur, np.uint8)
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(12)
+    prm = projection_params(cam4, 0.0, bounds, th, check_orientation)
+    m = np.full(max(len(kp_cur), 1), -1, np.int32)
+    n = C.c_int(0)
+    ex._check(lib().orbhip_search_by_projection_keyframe(ex._h, _ptr(kp_kf), _ptr(world), _ptr(rng_), _ptr(flags), _ptr(d1), len(kp_kf),
+                                                         _ptr(kp_cur), _ptr(d2), None if oc is None else _ptr(oc), len(kp_cur),
+                                                         _ptr(T), C.byref(prm), int(orb_dist), _ptr(m), C.byref(n)))
     return m[:len(kp_cur)], n.value
 
 
