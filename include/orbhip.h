@@ -301,6 +301,25 @@ int orbhip_search_by_projection_keyframe(orbhip_extractor* e, const orbhip_keypo
                                          const float* Tcw, const orbhip_projection_params* prm, int orb_dist,
                                          int* match_cur, int* nmatches);
 
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (src/ORBmatcher.cc:156-285;
+ * Tracking::TrackReferenceKeyFrame and relocalisation) on plain arrays. The DBoW2 feature vectors
+ * (pKF->mFeatVec, F.mFeatVec: vocabulary node -> feature indices) arrive as one node id per feature
+ * (0xFFFFFFFF: the feature is in no node); computing them (the vocabulary transform) stays with the
+ * caller. Key frame: d_kp_kf = mvKeysUn (angle), descriptors, node ids, d_flags_kf bit 0 =
+ * "GetMapPointMatches()[i] exists and is not bad". Frame: d_kp_f = mvKeys (angle), descriptors, node
+ * ids. nnratio = mfNNratio, check_orientation = mbCheckOrientation. d_match_f[f][i2] = index of the
+ * key-frame feature whose map point vpMapPointMatches[i2] receives, -1 = NULL; d_nmatches[f] = the
+ * returned count. At most 4096 keypoint slots per frame (the node grouping is sorted on chip). */
+int orbhip_search_by_bow_batch_device(orbhip_extractor* e, int nframes, int cap, const orbhip_keypoint* d_kp_kf,
+                                      const uint8_t* d_desc_kf, const uint32_t* d_node_kf, const uint8_t* d_flags_kf,
+                                      const int* d_cnt_kf, const orbhip_keypoint* d_kp_f, const uint8_t* d_desc_f,
+                                      const uint32_t* d_node_f, const int* d_cnt_f, float nnratio, int check_orientation,
+                                      int* d_match_f, int* d_nmatches, void* stream);
+/* The same for one key frame / frame with host arrays; waits for the result. */
+int orbhip_search_by_bow(orbhip_extractor* e, const orbhip_keypoint* kp_kf, const uint8_t* desc_kf, const uint32_t* node_kf,
+                         const uint8_t* flags_kf, int n1, const orbhip_keypoint* kp_f, const uint8_t* desc_f,
+                         const uint32_t* node_f, int n2, float nnratio, int check_orientation, int* match_f, int* nmatches);
+
 /* ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, const float th)
  * (src/ORBmatcher.cc:46-127, called by Tracking::SearchLocalPoints) on plain arrays.
  * A map point is described by what that function reads from it: the fields Frame::isInFrustum

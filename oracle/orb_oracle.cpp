@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstring>
 #include <list>
+#include <map>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -1395,6 +1396,95 @@ int orbo_search_by_projection_keyframe(const orbo_keypoint* k_kf, const float* w
         for (int i = 0; i < HISTO_LENGTH; i++) {
             if (i == ind1 || i == ind2 || i == ind3) continue;
             for (int idx2 : rotHist[i]) { match_cur[idx2] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (src/ORBmatcher.cc:156-285)
+ * on plain arrays. node_kf / node_f: the vocabulary node of every feature (0xFFFFFFFF: none), from
+ * which the DBoW2 feature vectors (std::map node -> indices in ascending order, as
+ * DBoW2::FeatureVector::addFeature builds them while the features are transformed in index order) are
+ * rebuilt. k_kf = pKF->mvKeysUn, k_f = F.mvKeys (angles), flags_kf bit 0 = "the key-frame feature has a
+ * map point that is not bad". match_f[i2] = index of the key-frame feature whose point
+ * vpMapPointMatches[i2] holds at the end, -1 = NULL. Returns nmatches. */
+int orbo_search_by_bow(const orbo_keypoint* k_kf, const uint8_t* desc_kf, const uint32_t* node_kf, const uint8_t* flags_kf, int n1,
+                       const orbo_keypoint* k_f, const uint8_t* desc_f, const uint32_t* node_f, int n2, float mfNNratio,
+                       int mbCheckOrientation, int* match_f) {
+    const int HISTO_LENGTH = 30, TH_LOW = 50;
+    std::map<uint32_t, std::vector<unsigned int>> vFeatVecKF, vFeatVecF;
+    for (int i = 0; i < n1; i++) if (node_kf[i] != 0xFFFFFFFFu) vFeatVecKF[node_kf[i]].push_back((unsigned)i);
+    for (int i = 0; i < n2; i++) if (node_f[i] != 0xFFFFFFFFu) vFeatVecF[node_f[i]].push_back((unsigned)i);
+    auto DescriptorDistance = [](const uint8_t* a, const uint8_t* b) {   /* src/ORBmatcher.cc:1611-1627 */
+        int dist = 0;
+        for (int i = 0; i < 8; i++) {
+            uint32_t pa, pb;
+            std::memcpy(&pa, a + 4 * i, 4); std::memcpy(&pb, b + 4 * i, 4);
+            unsigned int v = pa ^ pb;
+            v = v - ((v >> 1) & 0x55555555);
+            v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+            dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+        }
+        return dist;
+    };
+    for (int i = 0; i < n2; i++) match_f[i] = -1;
+    int nmatches = 0;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    auto KFit = vFeatVecKF.begin(), KFend = vFeatVecKF.end();
+    auto Fit = vFeatVecF.begin(), Fend = vFeatVecF.end();
+    while (KFit != KFend && Fit != Fend) {
+        if (KFit->first == Fit->first) {
+            const std::vector<unsigned int>& vIndicesKF = KFit->second;
+            const std::vector<unsigned int>& vIndicesF = Fit->second;
+            for (size_t iKF = 0; iKF < vIndicesKF.size(); iKF++) {
+                const unsigned int realIdxKF = vIndicesKF[iKF];
+                if (!(flags_kf[realIdxKF] & 1)) continue;      /* !pMP or pMP->isBad() */
+                const uint8_t* dKF = desc_kf + 32 * (size_t)realIdxKF;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                for (size_t iF = 0; iF < vIndicesF.size(); iF++) {
+                    const unsigned int realIdxF = vIndicesF[iF];
+                    if (match_f[realIdxF] >= 0) continue;
+                    const int dist = DescriptorDistance(dKF, desc_f + 32 * (size_t)realIdxF);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = (int)realIdxF; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 <= TH_LOW) {
+                    if (static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
+                        match_f[bestIdxF] = (int)realIdxKF;
+                        if (mbCheckOrientation) {
+                            float rot = k_kf[realIdxKF].angle - k_f[bestIdxF].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)std::round(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back(bestIdxF);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            KFit++;
+            Fit++;
+        } else if (KFit->first < Fit->first) {
+            KFit = vFeatVecKF.lower_bound(Fit->first);
+        } else {
+            Fit = vFeatVecF.lower_bound(KFit->first);
+        }
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        int max1 = 0, max2 = 0, max3 = 0;                      /* ComputeThreeMaxima (src/ORBmatcher.cc:1566-1607) */
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int sz = (int)rotHist[i].size();
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx : rotHist[i]) { match_f[idx] = -1; nmatches--; }
         }
     }
     return nmatches;

@@ -125,6 +125,10 @@ int orbo_search_by_projection_keyframe(const orbo_keypoint* k_kf, const float* w
                                        const uint8_t* desc_cur, const uint8_t* occupied_cur, int n2, const float* Tcw,
                                        const float* cam, const float* bounds, const float* scale_factors, float scale_factor,
                                        int nlevels, float th, int ORBdist, int mbCheckOrientation, int* match_cur);
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (src/ORBmatcher.cc:156-285). */
+int orbo_search_by_bow(const orbo_keypoint* k_kf, const uint8_t* desc_kf, const uint32_t* node_kf, const uint8_t* flags_kf, int n1,
+                       const orbo_keypoint* k_f, const uint8_t* desc_f, const uint32_t* node_f, int n2, float mfNNratio,
+                       int mbCheckOrientation, int* match_f);
 /* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:46-127). */
 typedef struct orbo_track_point { float proj_x, proj_y, proj_xr, view_cos; int32_t level, flags; } orbo_track_point;
 int orbo_search_map_points(const orbo_track_point* mp, const uint8_t* desc_mp, int n1, const orbo_keypoint* k,

@@ -89,6 +89,7 @@ def lib():
                                          C.c_float, C.c_void_p]
         L.orbo_search_by_projection_keyframe.argtypes = [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4 + \
             [C.c_float, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
+        L.orbo_search_by_bow.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.orbo_libm_logf.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orbo_libm_sincos.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orbo_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
@@ -413,3 +414,15 @@ def search_by_projection_keyframe(kp_kf, world_kf, dist_range_kf, flags_kf, desc
                                                  _ptr(sf), float(np.float32(scale_factor)), len(sf), float(th), int(orb_dist),
                                                  int(bool(check_orientation)), _ptr(m))
     return m[:len(kp_cur)], n
+
+
+def search_by_bow(kp_kf, desc_kf, node_kf, flags_kf, kp_f, desc_f, node_f, nnratio=0.7, check_orientation=True):
+    """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches): returns (match_f, nmatches), match_f[i2] = key-frame feature or -1."""
+    kp_kf = np.ascontiguousarray(kp_kf, KP_DTYPE); kp_f = np.ascontiguousarray(kp_f, KP_DTYPE)
+    d1 = np.ascontiguousarray(desc_kf, np.uint8); d2 = np.ascontiguousarray(desc_f, np.uint8)
+    n1 = np.ascontiguousarray(node_kf, np.uint32); n2 = np.ascontiguousarray(node_f, np.uint32)
+    fl = np.ascontiguousarray(flags_kf, np.uint8)
+    m = np.full(max(len(kp_f), 1), -1, np.int32)
+    n = lib().orbo_search_by_bow(_ptr(kp_kf), _ptr(d1), _ptr(n1), _ptr(fl), len(kp_kf), _ptr(kp_f), _ptr(d2), _ptr(n2), len(kp_f),
+                                 float(nnratio), int(bool(check_orientation)), _ptr(m))
+    return m[:len(kp_f)], n

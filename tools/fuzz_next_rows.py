@@ -108,6 +108,20 @@ def main():
         gm4, gn4 = orbhip.SearchByProjectionKeyFrame(ex, u1, world, drange, flags & 1, d1, u2, d2, occ_kf, Tcw, cam[:4], bounds, th, odist, ori)
         if gn4 != on4 or not np.array_equal(gm4, om4):
             bad += 1; print(tag, "KEYFRAME PROJECTION MISMATCH", gn4, on4, int((gm4 != om4).sum()))
+        # the bag-of-words matcher with synthetic node ids (a hash of descriptor bits; now and then a feature without a node)
+        nn = int(rng.choice([1, 7, 100, 1000]))
+        def nodes(d):
+            v = (d[:, 0].astype(np.uint32) | (d[:, 9].astype(np.uint32) << 8)) & 0xFFF
+            out = (v * 2654435761 % nn).astype(np.uint32) * 11 + 5
+            out[rng.random(len(d)) < 0.03] = 0xFFFFFFFF
+            return out
+        nk, nf = nodes(d1), nodes(d2)
+        ratio_b = float(rng.choice([0.6, 0.7, 0.9]))
+        if max(len(u1), len(u2)) <= 4096:
+            om5, on5 = O.search_by_bow(u1, d1, nk, flags & 1, k2, d2, nf, ratio_b, ori)
+            gm5, gn5 = orbhip.SearchByBoW(ex, u1, d1, nk, flags & 1, k2, d2, nf, ratio_b, ori)
+            if gn5 != on5 or not np.array_equal(gm5, om5):
+                bad += 1; print(tag, "BOW MISMATCH", gn5, on5, int((gm5 != om5).sum()))
         # the local-map matcher: the first view's keypoints (several copies, shuffled) as map points
         copies = int(rng.integers(1, 4))
         src = np.tile(np.arange(len(u1)), copies); rng.shuffle(src)

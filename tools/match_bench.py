@@ -181,6 +181,51 @@ def main():
         pass
     print(json.dumps(out))
 
+    # ---- ORBmatcher::SearchByBoW(pKF, F): last frame as key frame, synthetic node ids (100 nodes, a hash of descriptor bits)
+    def nodes(d):
+        v = (d[..., 0].astype(np.uint32) | (d[..., 7].astype(np.uint32) << 8)) & 0xFFF
+        return (v * 2654435761 % 100).astype(np.uint32) * 37 + 1000
+    hd2 = d2.cpu().numpy()
+    nk, nf = nodes(hd1), nodes(hd2)
+    fl = (flags & 1).astype(np.uint8)
+    with torch.cuda.stream(stream):
+        d_nk, d_nf, d_fl = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (nk, nf, fl))
+    stream.synchronize()
+
+    def step_bow():
+        orbhip.search_by_bow_batch_device(ex, n, cap, k1.data_ptr(), d1.data_ptr(), d_nk.data_ptr(), d_fl.data_ptr(), c1.data_ptr(),
+                                          k2.data_ptr(), d2.data_ptr(), d_nf.data_ptr(), c2.data_ptr(), 0.7, True, match.data_ptr(),
+                                          nm.data_ptr(), stream=sp)
+    step_bow(); stream.synchronize()
+    with torch.cuda.stream(stream):
+        e0.record(stream)
+        for _ in range(args.steps):
+            step_bow()
+        e1.record(stream)
+    stream.synchronize()
+    ms = e0.elapsed_time(e1) / args.steps
+    hm, hn = match.cpu().numpy(), nm.cpu().numpy()
+    out = {"op": "SearchByBoW(pKF, F)", "pairs": n, "image": [w, h], "nodes": 100, "ms_per_batch": round(ms, 3),
+           "pairs_per_s": round(n / ms * 1e3, 1), "mean_matches": float(hn.mean())}
+    try:
+        from oracle import orb_oracle as O
+        hk1, hk2 = k1.cpu().numpy(), k2.cpu().numpy()
+        hc1, hc2 = c1.cpu().numpy(), c2.cpu().numpy()
+        m = min(args.cpu_pairs, n)
+        ok, t = True, 0.0
+        for i in range(m):
+            a1 = np.zeros(hc1[i], orbhip.KP_DTYPE); a1[:] = hk1[i, :hc1[i]].view(orbhip.KP_DTYPE).reshape(-1)
+            a2 = np.zeros(hc2[i], orbhip.KP_DTYPE); a2[:] = hk2[i, :hc2[i]].view(orbhip.KP_DTYPE).reshape(-1)
+            t0 = time.perf_counter()
+            om, on = O.search_by_bow(a1, hd1[i, :hc1[i]], nk[i, :hc1[i]], fl[i, :hc1[i]], a2, hd2[i, :hc2[i]], nf[i, :hc2[i]], 0.7, True)
+            t += time.perf_counter() - t0
+            ok = ok and on == hn[i] and np.array_equal(om, hm[i, :hc2[i]])
+        out["oracle_parity_first_pairs"] = bool(ok)
+        out["cpu_oracle_pairs_per_s_one_thread"] = round(m / t, 1)
+    except ImportError:
+        pass
+    print(json.dumps(out))
+
 
 if __name__ == "__main__":
     main()

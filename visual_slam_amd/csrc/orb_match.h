@@ -916,3 +916,178 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_map(const TrackPt* __rest
         if (lane == 0) nmatches_out[f] = made;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)
+// (reference src/ORBmatcher.cc:156-285; Tracking::TrackReferenceKeyFrame and relocalisation) on plain
+// arrays. The DBoW2 feature vectors (vocabulary node -> ascending feature indices, nodes ascending)
+// arrive as one node id per feature; the matching itself is Hamming work: inside every node the two
+// frames share, each key-frame feature that has a map point takes the closest frame feature of
+// that node that no earlier feature took, if it is close enough and distinctly closer than the
+// second closest.
+//
+// A frame feature lies in exactly one node, so the nodes are independent and only the loop inside
+// a node is ordered. The workgroup sorts (node, index) keys of both sides in LDS (bitonic), cuts
+// the key-frame side into runs of equal node and deals the runs to its waves; a wave walks its run in
+// order, the lanes sharing the scan over the node's frame features (first of equal distances wins:
+// minimum over (distance, position in the node)).
+// ------------------------------------------------------------------------------------------------
+#define MB_NONE_NODE 0xFFFFFFFFu   // node id of a feature that is in no feature vector
+#define MB_LDS_PER_SLOT 22          // dynamic LDS bytes per (power-of-two padded) feature slot
+
+// Bitonic sort of a[0..n) (n a power of two) in LDS by the whole workgroup, ascending.
+__device__ __forceinline__ void mb_sort(unsigned long long* a, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < n / 2; t += MP_THREADS) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // the lower index of the pair
+                const int p = i | j;
+                const unsigned long long x = a[i], y = a[p];
+                const bool up = (i & k) == 0;
+                if ((x > y) == up) { a[i] = y; a[p] = x; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(MP_THREADS) void k_search_bow(const GridKp* __restrict__ kp1, const uint8_t* __restrict__ desc1,
+                                                           const uint32_t* __restrict__ node1, const uint8_t* __restrict__ flags1,
+                                                           const int* __restrict__ cnt1, const GridKp* __restrict__ kp2,
+                                                           const uint8_t* __restrict__ desc2, const uint32_t* __restrict__ node2,
+                                                           const int* __restrict__ cnt2, int cap, int npad, float nnratio,
+                                                           int check_orientation, int* __restrict__ match2, int* __restrict__ nmatches_out) {
+    extern __shared__ __align__(16) uint8_t mb_smem[];
+    unsigned long long* A = reinterpret_cast<unsigned long long*>(mb_smem);   // key frame: node << 16 | index, sorted
+    unsigned long long* B = A + npad;                                          // frame: the same
+    uint32_t* run_start = reinterpret_cast<uint32_t*>(B + npad);              // scan of the run heads, then first position of every run
+    uint8_t* taken2 = reinterpret_cast<uint8_t*>(run_start + npad);           // frame feature already holds a match
+    uint8_t* bin2 = taken2 + npad;                                            // rotation bin of that match, 0xFF = none
+    __shared__ uint32_t s_tmp[MP_WAVES];
+    __shared__ int s_hist[MT_HISTO];
+    __shared__ int s_count[2];                                                // matches made, matches removed
+    const int tid = threadIdx.x, lane = tid & 63, f = blockIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t o = (size_t)f * cap;
+    const int n1 = min(cnt1[f], cap), n2 = min(cnt2[f], cap);
+    int* m2 = match2 + o;
+    for (int i = tid; i < npad; i += MP_THREADS) {
+        const uint32_t na = i < n1 ? node1[o + i] : MB_NONE_NODE, nb = i < n2 ? node2[o + i] : MB_NONE_NODE;
+        A[i] = ((unsigned long long)na << 16) | (unsigned)i;
+        B[i] = ((unsigned long long)nb << 16) | (unsigned)i;
+        taken2[i] = 0;
+        bin2[i] = 0xFF;
+        if (i < n2) m2[i] = -1;
+    }
+    if (tid < MT_HISTO) s_hist[tid] = 0;
+    if (tid < 2) s_count[tid] = 0;
+    __syncthreads();
+    mb_sort(A, npad);
+    mb_sort(B, npad);
+    // runs of equal node on the key-frame side (features without a node sort to the end and form no run)
+    for (int i = tid; i < npad; i += MP_THREADS) {
+        const uint32_t nd = (uint32_t)(A[i] >> 16);
+        run_start[i] = (nd != MB_NONE_NODE && (i == 0 || (uint32_t)(A[i - 1] >> 16) != nd)) ? 1u : 0u;
+    }
+    __syncthreads();
+    uint32_t mine[4];                                          // npad <= 4096: at most 4 positions per thread
+    const int per = npad / MP_THREADS > 0 ? npad / MP_THREADS : 1;
+    // exclusive scan over consecutive chunks (thread t owns positions t*per .. t*per+per-1)
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int i = tid * per + k; mine[k] = (k < per && i < npad) ? run_start[i] : 0u; s += mine[k]; }
+    const uint32_t inc = wave_scan_incl(s);
+    if (lane == 63) s_tmp[wv] = inc;
+    __syncthreads();
+    uint32_t off = 0, nruns = 0;
+#pragma unroll
+    for (int w = 0; w < MP_WAVES; w++) { if (w < wv) off += s_tmp[w]; nruns += s_tmp[w]; }
+    uint32_t run = off + inc - s;
+    __syncthreads();                                           // every thread has read its flags: the array is reused for the run starts
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = tid * per + k;
+        if (mine[k]) { run_start[run] = (uint32_t)i; run++; }
+    }
+    __syncthreads();
+
+    int made = 0;
+    for (uint32_t r = wv; r < nruns; r += MP_WAVES) {
+        const int start = (int)run_start[r];
+        const uint32_t nd = (uint32_t)(A[start] >> 16);
+        // the frame's features of this node: B[fs .. fe)
+        int lo = 0, hi = npad;                                 // lower bound of nd << 16
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((uint32_t)(B[mid] >> 16) < nd) lo = mid + 1; else hi = mid; }
+        const int fs = lo;
+        hi = npad;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((uint32_t)(B[mid] >> 16) <= nd) lo = mid + 1; else hi = mid; }
+        const int fe = lo;
+        if (fe == fs) continue;                                // the frame has no feature in this node
+        for (int ia = start; ia < npad && (uint32_t)(A[ia] >> 16) == nd; ia++) {
+            const int i1 = (int)(A[ia] & 0xFFFF);
+            if (!(flags1[o + i1] & 1)) continue;               // no map point, or a bad one (src/ORBmatcher.cc:188-194)
+            const uint4* d1p = reinterpret_cast<const uint4*>(desc1 + (o + i1) * 32);
+            const uint4 da = d1p[0], db = d1p[1];
+            uint32_t best = 0xFFFFFFFFu, second = 0x7FFFFFFFu;  // distance << 16 | position in the node; second-best distance
+            for (int c = fs + lane; c < fe; c += 64) {
+                const int i2 = (int)(B[c] & 0xFFFF);
+                if (taken2[i2]) continue;                      // src/ORBmatcher.cc:206-207
+                const uint4* d2p = reinterpret_cast<const uint4*>(desc2 + (o + i2) * 32);
+                const uint4 x = d2p[0], y = d2p[1];
+                const unsigned dist = __popc(x.x ^ da.x) + __popc(x.y ^ da.y) + __popc(x.z ^ da.z) + __popc(x.w ^ da.w) +
+                                      __popc(y.x ^ db.x) + __popc(y.y ^ db.y) + __popc(y.z ^ db.z) + __popc(y.w ^ db.w);
+                const uint32_t key = (dist << 16) | (uint32_t)(c - fs);
+                if (key < best) { second = min(second, best == 0xFFFFFFFFu ? 0x7FFFFFFFu : best >> 16); best = key; }
+                else second = min(second, dist);
+            }
+            uint32_t wbest = best;
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) wbest = min(wbest, (uint32_t)__shfl_xor((int)wbest, sh, 64));
+            if (wbest == 0xFFFFFFFFu) continue;                // every feature of the node is taken: bestDist1 stays 256
+            uint32_t other = best == wbest ? second : min(second, best == 0xFFFFFFFFu ? 0x7FFFFFFFu : best >> 16);
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) other = min(other, (uint32_t)__shfl_xor((int)other, sh, 64));
+            const int bestDist1 = (int)(wbest >> 16);
+            const int bestDist2 = other == 0x7FFFFFFFu ? 256 : (int)other;
+            if (bestDist1 <= MT_TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {   // src/ORBmatcher.cc:225-227
+                const int i2 = (int)(B[fs + (int)(wbest & 0xFFFF)] & 0xFFFF);
+                made++;
+                if (lane == 0) {
+                    taken2[i2] = 1;
+                    m2[i2] = i1;
+                    if (check_orientation) {
+                        float rot = kp1[o + i1].angle - kp2[o + i2].angle;
+                        if (rot < 0.0f) rot += 360.0f;
+                        int bin = (int)roundf(rot * (1.0f / MT_HISTO));
+                        if (bin == MT_HISTO) bin = 0;
+                        bin2[i2] = (uint8_t)bin;
+                        atomicAdd(&s_hist[bin], 1);
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0 && made) atomicAdd(&s_count[0], made);
+    __syncthreads();                                           // all matches are made, their stores visible to the workgroup
+    int bad = 0;
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;   // ComputeThreeMaxima (src/ORBmatcher.cc:1566-1607)
+        for (int i = 0; i < MT_HISTO; i++) {
+            const int sz = s_hist[i];
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = tid; i < n2; i += MP_THREADS) {
+            const int b = bin2[i];
+            if (b != 0xFF && b != ind1 && b != ind2 && b != ind3) { m2[i] = -1; bad++; }   // src/ORBmatcher.cc:272-281
+        }
+    }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) bad += __shfl_xor(bad, sh, 64);
+    if (lane == 0 && bad) atomicAdd(&s_count[1], bad);
+    __syncthreads();
+    if (tid == 0) nmatches_out[f] = s_count[0] - s_count[1];
+}

@@ -1353,6 +1353,77 @@ int orbhip_search_by_projection_keyframe(orbhip_extractor* e, const orbhip_keypo
     return ORBHIP_OK;
 }
 
+int orbhip_search_by_bow_batch_device(orbhip_extractor* e, int nframes, int cap, const orbhip_keypoint* d_kp_kf,
+                                      const uint8_t* d_desc_kf, const uint32_t* d_node_kf, const uint8_t* d_flags_kf,
+                                      const int* d_cnt_kf, const orbhip_keypoint* d_kp_f, const uint8_t* d_desc_f,
+                                      const uint32_t* d_node_f, const int* d_cnt_f, float nnratio, int check_orientation,
+                                      int* d_match_f, int* d_nmatches, void* stream) {
+    if (!e || nframes < 1 || cap < 1 || !d_kp_kf || !d_desc_kf || !d_node_kf || !d_flags_kf || !d_cnt_kf || !d_kp_f || !d_desc_f ||
+        !d_node_f || !d_cnt_f || !d_match_f || !d_nmatches)
+        return ORBHIP_ERR_ARG;
+    if (cap > 4096) { e->err = "too many keypoints per frame for the on-chip sort of the bag-of-words matcher"; return ORBHIP_ERR_CAPACITY; }
+    int npad = 64;
+    while (npad < cap) npad <<= 1;
+    const size_t lds = (size_t)MB_LDS_PER_SLOT * npad;
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    if (lds > 40 * 1024)
+        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_bow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_search_bow, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const GridKp*>(d_kp_kf), d_desc_kf, d_node_kf,
+                       d_flags_kf, d_cnt_kf, reinterpret_cast<const GridKp*>(d_kp_f), d_desc_f, d_node_f, d_cnt_f, cap, npad, nnratio,
+                       check_orientation, d_match_f, d_nmatches);
+    HIP_TRY(e, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_search_by_bow(orbhip_extractor* e, const orbhip_keypoint* kp_kf, const uint8_t* desc_kf, const uint32_t* node_kf,
+                         const uint8_t* flags_kf, int n1, const orbhip_keypoint* kp_f, const uint8_t* desc_f,
+                         const uint32_t* node_f, int n2, float nnratio, int check_orientation, int* match_f, int* nmatches) {
+    if (!e || n1 < 0 || n2 < 0 || !nmatches) return ORBHIP_ERR_ARG;
+    if (n2 > 0 && !match_f) return ORBHIP_ERR_ARG;
+    for (int i = 0; i < n2; i++) match_f[i] = -1;
+    if (n1 == 0 || n2 == 0) { *nmatches = 0; return ORBHIP_OK; }
+    if (!kp_kf || !desc_kf || !node_kf || !flags_kf || !kp_f || !desc_f || !node_f) return ORBHIP_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    const int cap = std::max(n1, n2);
+    auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
+    const size_t kpb = up((size_t)cap * sizeof(orbhip_keypoint)), db = up((size_t)cap * 32), nb = up((size_t)cap * 4), fb = up((size_t)cap);
+    const size_t need = 64 + 2 * kpb + 2 * db + 3 * nb + fb;
+    if (need > e->d_st_tmp_bytes) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        dfree(e->d_st_tmp);
+        HIP_TRY(e, hipMalloc(&e->d_st_tmp, need));
+        e->d_st_tmp_bytes = need;
+    }
+    uint8_t* p = e->d_st_tmp;
+    int* d_cnt = reinterpret_cast<int*>(p); p += 64;           // [0] n1, [1] n2, [2] matches
+    orbhip_keypoint* d_k1 = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
+    orbhip_keypoint* d_k2 = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
+    uint8_t* d_d1 = p; p += db;
+    uint8_t* d_d2 = p; p += db;
+    uint32_t* d_n1 = reinterpret_cast<uint32_t*>(p); p += nb;
+    uint32_t* d_n2 = reinterpret_cast<uint32_t*>(p); p += nb;
+    int* d_m = reinterpret_cast<int*>(p); p += nb;
+    uint8_t* d_f = p;
+    const int cnt[3] = {n1, n2, 0};
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(d_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_k1, kp_kf, (size_t)n1 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_d1, desc_kf, (size_t)n1 * 32, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_n1, node_kf, (size_t)n1 * 4, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_f, flags_kf, (size_t)n1, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_k2, kp_f, (size_t)n2 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_d2, desc_f, (size_t)n2 * 32, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_n2, node_f, (size_t)n2 * 4, hipMemcpyHostToDevice));
+    int rc = orbhip_search_by_bow_batch_device(e, 1, cap, d_k1, d_d1, d_n1, d_f, d_cnt, d_k2, d_d2, d_n2, d_cnt + 1, nnratio,
+                                               check_orientation, d_m, d_cnt + 2, nullptr);
+    if (rc) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(match_f, d_m, (size_t)n2 * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(nmatches, d_cnt + 2, sizeof(int), hipMemcpyDeviceToHost));
+    return ORBHIP_OK;
+}
+
 int orbhip_search_map_points_batch_device(orbhip_extractor* e, int nframes, int cap_mp, const orbhip_track_point* d_mp,
                                           const uint8_t* d_desc_mp, const int* d_cnt_mp, int cap_kp,
                                           const orbhip_keypoint* d_kp, const uint8_t* d_desc, const float* d_uright,

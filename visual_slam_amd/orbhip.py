@@ -39,6 +39,7 @@ EXPORTS = [
     "orbhip_search_map_points", "orbhip_search_map_points_batch_device",
     "orbhip_is_in_frustum", "orbhip_is_in_frustum_batch_device", "orbhip_debug_logf",
     "orbhip_search_by_projection_keyframe", "orbhip_search_by_projection_keyframe_batch_device",
+    "orbhip_search_by_bow", "orbhip_search_by_bow_batch_device",
 ]
 
 
@@ -108,6 +109,8 @@ def lib():
         L.orbhip_debug_sincos.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]
         L.orbhip_search_by_projection_keyframe.argtypes = [vp] * 6 + [C.c_int] + [vp] * 3 + [C.c_int, vp, vp, C.c_int, vp, ip]
         L.orbhip_search_by_projection_keyframe_batch_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 12 + [C.c_int, vp, vp, vp]
+        L.orbhip_search_by_bow.argtypes = [vp] * 5 + [C.c_int] + [vp] * 3 + [C.c_int, C.c_float, C.c_int, vp, ip]
+        L.orbhip_search_by_bow_batch_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 9 + [C.c_float, C.c_int, vp, vp, vp]
         L.orbhip_debug_logf.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
         L.orbhip_is_in_frustum.argtypes = [vp, vp, C.c_int, vp, vp, C.c_float, vp, ip]
         L.orbhip_is_in_frustum_batch_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_float, vp, vp, vp]
@@ -224,6 +227,28 @@ def SearchByProjectionKeyFrame(ex, kp_kf, world_kf, dist_range_kf, flags_kf, des
                                                          _ptr(kp_cur), _ptr(d2), None if oc is None else _ptr(oc), len(kp_cur),
                                                          _ptr(T), C.byref(prm), int(orb_dist), _ptr(m), C.byref(n)))
     return m[:len(kp_cur)], n.value
+
+
+def SearchByBoW(ex, kp_kf, desc_kf, node_kf, flags_kf, kp_f, desc_f, node_f, nnratio=0.7, check_orientation=True):
+    """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) (reference src/ORBmatcher.cc:156-285) on the device; node_*:
+    vocabulary node of every feature (0xFFFFFFFF: none). Returns (match_f, nmatches)."""
+    kp_kf = np.ascontiguousarray(kp_kf, KP_DTYPE); kp_f = np.ascontiguousarray(kp_f, KP_DTYPE)
+    d1 = np.ascontiguousarray(desc_kf, np.uint8); d2 = np.ascontiguousarray(desc_f, np.uint8)
+    n1 = np.ascontiguousarray(node_kf, np.uint32); n2 = np.ascontiguousarray(node_f, np.uint32)
+    fl = np.ascontiguousarray(flags_kf, np.uint8)
+    m = np.full(max(len(kp_f), 1), -1, np.int32)
+    n = C.c_int(0)
+    ex._check(lib().orbhip_search_by_bow(ex._h, _ptr(kp_kf), _ptr(d1), _ptr(n1), _ptr(fl), len(kp_kf), _ptr(kp_f), _ptr(d2), _ptr(n2),
+                                         len(kp_f), float(nnratio), int(bool(check_orientation)), _ptr(m), C.byref(n)))
+    return m[:len(kp_f)], n.value
+
+
+def search_by_bow_batch_device(ex, nframes, cap, d_kp_kf, d_desc_kf, d_node_kf, d_flags_kf, d_cnt_kf, d_kp_f, d_desc_f, d_node_f,
+                               d_cnt_f, nnratio, check_orientation, d_match_f, d_nmatches, stream=None):
+    """Raw-pointer batch call of SearchByBoW on device-resident key frame / frame pairs."""
+    ex._check(lib().orbhip_search_by_bow_batch_device(ex._h, nframes, cap, d_kp_kf, d_desc_kf, d_node_kf, d_flags_kf, d_cnt_kf, d_kp_f,
+                                                      d_desc_f, d_node_f, d_cnt_f, float(nnratio), int(bool(check_orientation)),
+                                                      d_match_f, d_nmatches, stream))
 
 
 def search_by_projection_batch_device(ex, nframes, cap, d_kp_last, d_world_last, d_flags_last, d_desc_last, d_cnt_last,
