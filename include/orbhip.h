@@ -320,6 +320,20 @@ int orbhip_search_by_bow(orbhip_extractor* e, const orbhip_keypoint* kp_kf, cons
                          const uint8_t* flags_kf, int n1, const orbhip_keypoint* kp_f, const uint8_t* desc_f,
                          const uint32_t* node_f, int n2, float nnratio, int check_orientation, int* match_f, int* nmatches);
 
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (src/ORBmatcher.cc:519-652,
+ * loop detection) in the same form: both sides give mvKeysUn, descriptors, node ids and flags (bit 0 =
+ * "the feature has a map point that is not bad"). d_match12[f][i1] = feature of key frame 2 whose map
+ * point vpMatches12[i1] receives, -1 = NULL. */
+int orbhip_search_by_bow_keyframes_batch_device(orbhip_extractor* e, int nframes, int cap, const orbhip_keypoint* d_kp1,
+                                                const uint8_t* d_desc1, const uint32_t* d_node1, const uint8_t* d_flags1,
+                                                const int* d_cnt1, const orbhip_keypoint* d_kp2, const uint8_t* d_desc2,
+                                                const uint32_t* d_node2, const uint8_t* d_flags2, const int* d_cnt2, float nnratio,
+                                                int check_orientation, int* d_match12, int* d_nmatches, void* stream);
+int orbhip_search_by_bow_keyframes(orbhip_extractor* e, const orbhip_keypoint* kp1, const uint8_t* desc1, const uint32_t* node1,
+                                   const uint8_t* flags1, int n1, const orbhip_keypoint* kp2, const uint8_t* desc2,
+                                   const uint32_t* node2, const uint8_t* flags2, int n2, float nnratio, int check_orientation,
+                                   int* match12, int* nmatches);
+
 /* ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, const float th)
  * (src/ORBmatcher.cc:46-127, called by Tracking::SearchLocalPoints) on plain arrays.
  * A map point is described by what that function reads from it: the fields Frame::isInFrustum

@@ -1490,6 +1490,92 @@ int orbo_search_by_bow(const orbo_keypoint* k_kf, const uint8_t* desc_kf, const 
     return nmatches;
 }
 
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (src/ORBmatcher.cc:519-652)
+ * on plain arrays, as orbo_search_by_bow: both sides give mvKeysUn, descriptors, node ids and flags (bit 0 =
+ * "has a map point that is not bad"). match12[i1] = feature of key frame 2 whose map point
+ * vpMatches12[i1] holds at the end, -1 = NULL. Returns nmatches. */
+int orbo_search_by_bow_keyframes(const orbo_keypoint* k1, const uint8_t* desc1, const uint32_t* node1, const uint8_t* flags1, int n1,
+                                 const orbo_keypoint* k2, const uint8_t* desc2, const uint32_t* node2, const uint8_t* flags2, int n2,
+                                 float mfNNratio, int mbCheckOrientation, int* match12) {
+    const int HISTO_LENGTH = 30, TH_LOW = 50;
+    std::map<uint32_t, std::vector<unsigned int>> vFeatVec1, vFeatVec2;
+    for (int i = 0; i < n1; i++) if (node1[i] != 0xFFFFFFFFu) vFeatVec1[node1[i]].push_back((unsigned)i);
+    for (int i = 0; i < n2; i++) if (node2[i] != 0xFFFFFFFFu) vFeatVec2[node2[i]].push_back((unsigned)i);
+    auto DescriptorDistance = [](const uint8_t* a, const uint8_t* b) {   /* src/ORBmatcher.cc:1611-1627 */
+        int dist = 0;
+        for (int i = 0; i < 8; i++) {
+            uint32_t pa, pb;
+            std::memcpy(&pa, a + 4 * i, 4); std::memcpy(&pb, b + 4 * i, 4);
+            unsigned int v = pa ^ pb;
+            v = v - ((v >> 1) & 0x55555555);
+            v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+            dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+        }
+        return dist;
+    };
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    std::vector<bool> vbMatched2((size_t)n2, false);
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    auto f1it = vFeatVec1.begin(), f1end = vFeatVec1.end();
+    auto f2it = vFeatVec2.begin(), f2end = vFeatVec2.end();
+    while (f1it != f1end && f2it != f2end) {
+        if (f1it->first == f2it->first) {
+            for (size_t i1 = 0, iend1 = f1it->second.size(); i1 < iend1; i1++) {
+                const size_t idx1 = f1it->second[i1];
+                if (!(flags1[idx1] & 1)) continue;             /* !pMP1 or bad */
+                const uint8_t* d1 = desc1 + 32 * idx1;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (size_t i2 = 0, iend2 = f2it->second.size(); i2 < iend2; i2++) {
+                    const size_t idx2 = f2it->second[i2];
+                    if (vbMatched2[idx2] || !(flags2[idx2] & 1)) continue;
+                    const int dist = DescriptorDistance(d1, desc2 + 32 * idx2);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = (int)idx2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 < TH_LOW) {
+                    if (static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
+                        match12[idx1] = bestIdx2;
+                        vbMatched2[bestIdx2] = true;
+                        if (mbCheckOrientation) {
+                            float rot = k1[idx1].angle - k2[bestIdx2].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)std::round(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back((int)idx1);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            f1it++;
+            f2it++;
+        } else if (f1it->first < f2it->first) {
+            f1it = vFeatVec1.lower_bound(f2it->first);
+        } else {
+            f2it = vFeatVec2.lower_bound(f1it->first);
+        }
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        int max1 = 0, max2 = 0, max3 = 0;                      /* ComputeThreeMaxima (src/ORBmatcher.cc:1566-1607) */
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int sz = (int)rotHist[i].size();
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx : rotHist[i]) { match12[idx] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 /* ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, const float th)
  * (src/ORBmatcher.cc:46-127; the matcher of Tracking::SearchLocalPoints) with RadiusByViewingCos
  * (:129-135) on plain arrays. mp[i] holds what the function reads from vpMapPoints[i]: mTrackProjX,

@@ -129,6 +129,10 @@ int orbo_search_by_projection_keyframe(const orbo_keypoint* k_kf, const float* w
 int orbo_search_by_bow(const orbo_keypoint* k_kf, const uint8_t* desc_kf, const uint32_t* node_kf, const uint8_t* flags_kf, int n1,
                        const orbo_keypoint* k_f, const uint8_t* desc_f, const uint32_t* node_f, int n2, float mfNNratio,
                        int mbCheckOrientation, int* match_f);
+/* ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) (src/ORBmatcher.cc:519-652). */
+int orbo_search_by_bow_keyframes(const orbo_keypoint* k1, const uint8_t* desc1, const uint32_t* node1, const uint8_t* flags1, int n1,
+                                 const orbo_keypoint* k2, const uint8_t* desc2, const uint32_t* node2, const uint8_t* flags2, int n2,
+                                 float mfNNratio, int mbCheckOrientation, int* match12);
 /* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:46-127). */
 typedef struct orbo_track_point { float proj_x, proj_y, proj_xr, view_cos; int32_t level, flags; } orbo_track_point;
 int orbo_search_map_points(const orbo_track_point* mp, const uint8_t* desc_mp, int n1, const orbo_keypoint* k,

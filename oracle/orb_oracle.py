@@ -90,6 +90,7 @@ def lib():
         L.orbo_search_by_projection_keyframe.argtypes = [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4 + \
             [C.c_float, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
         L.orbo_search_by_bow.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.orbo_search_by_bow_keyframes.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.orbo_libm_logf.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orbo_libm_sincos.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orbo_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
@@ -426,3 +427,15 @@ def search_by_bow(kp_kf, desc_kf, node_kf, flags_kf, kp_f, desc_f, node_f, nnrat
     n = lib().orbo_search_by_bow(_ptr(kp_kf), _ptr(d1), _ptr(n1), _ptr(fl), len(kp_kf), _ptr(kp_f), _ptr(d2), _ptr(n2), len(kp_f),
                                  float(nnratio), int(bool(check_orientation)), _ptr(m))
     return m[:len(kp_f)], n
+
+
+def search_by_bow_keyframes(kp1, desc1, node1, flags1, kp2, desc2, node2, flags2, nnratio=0.75, check_orientation=True):
+    """ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12): returns (match12, nmatches), match12[i1] = feature of key frame 2 or -1."""
+    kp1 = np.ascontiguousarray(kp1, KP_DTYPE); kp2 = np.ascontiguousarray(kp2, KP_DTYPE)
+    d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+    n1 = np.ascontiguousarray(node1, np.uint32); n2 = np.ascontiguousarray(node2, np.uint32)
+    f1 = np.ascontiguousarray(flags1, np.uint8); f2 = np.ascontiguousarray(flags2, np.uint8)
+    m = np.full(max(len(kp1), 1), -1, np.int32)
+    n = lib().orbo_search_by_bow_keyframes(_ptr(kp1), _ptr(d1), _ptr(n1), _ptr(f1), len(kp1), _ptr(kp2), _ptr(d2), _ptr(n2), _ptr(f2),
+                                           len(kp2), float(nnratio), int(bool(check_orientation)), _ptr(m))
+    return m[:len(kp1)], n

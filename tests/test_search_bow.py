@@ -107,3 +107,47 @@ def test_hip_search_by_bow_edge_cases():
         big = np.zeros(5000, orbhip.KP_DTYPE)
         orbhip.SearchByBoW(ex, big, np.zeros((5000, 32), np.uint8), np.zeros(5000, np.uint32), np.ones(5000, np.uint8),
                            s["k2"], s["d2"], s["n2"])
+
+
+# ---- SearchByBoW(pKF1, pKF2, vpMatches12) (reference src/ORBmatcher.cc:519-652)
+
+def test_oracle_bow_keyframes_properties():
+    from oracle import orb_oracle as O
+    s = scenario(640, 480, 98, 4, 2)
+    rng = np.random.default_rng(8)
+    f2 = (rng.random(len(s["k2"])) < 0.7).astype(np.uint8)
+    m, n = O.search_by_bow_keyframes(s["k1"], s["d1"], s["n1"], s["flags"], s["k2"], s["d2"], s["n2"], f2, 0.75, True)
+    got = m >= 0
+    assert n == got.sum() and n > 100
+    assert np.all(s["flags"][got] & 1) and np.all(f2[m[got]] & 1)          # both features carry a good map point
+    assert np.all(s["n1"][got] == s["n2"][m[got]])
+    assert len(np.unique(m[got])) == got.sum()
+    # against the frame variant with all of side 2 eligible: the same pairs except for the strict TH_LOW test
+    allf = np.ones(len(s["k2"]), np.uint8)
+    m12, n12 = O.search_by_bow_keyframes(s["k1"], s["d1"], s["n1"], s["flags"], s["k2"], s["d2"], s["n2"], allf, 0.7, False)
+    mf, nf = O.search_by_bow(s["k1"], s["d1"], s["n1"], s["flags"], s["k2"], s["d2"], s["n2"], 0.7, False)
+    inv = np.full(len(s["k1"]), -1, np.int32)
+    inv[mf[mf >= 0]] = np.nonzero(mf >= 0)[0]
+    differ = np.nonzero(inv != m12)[0]
+    assert n12 <= nf and len(differ) <= nf - n12 + 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,nnodes,ratio,ori", [(1241, 376, 100, 0.75, True), (640, 480, 5, 0.9, False), (752, 480, 1000, 0.6, True)])
+def test_hip_search_by_bow_keyframes_matches_oracle(w, h, nnodes, ratio, ori):
+    from oracle import orb_oracle as O
+    from visual_slam_amd import orbhip
+    s = scenario(w, h, 99, 5, -2, nnodes=nnodes, prm=(1500, 1.2, 8, 20, 7))
+    rng = np.random.default_rng(9)
+    f2 = (rng.random(len(s["k2"])) < 0.75).astype(np.uint8)
+    om, on = O.search_by_bow_keyframes(s["k1"], s["d1"], s["n1"], s["flags"], s["k2"], s["d2"], s["n2"], f2, ratio, ori)
+    ex = orbhip.ORBextractor(1500, 1.2, 8, 20, 7)
+    gm, gn = orbhip.SearchByBoWKeyFrames(ex, s["k1"], s["d1"], s["n1"], s["flags"], s["k2"], s["d2"], s["n2"], f2, ratio, ori)
+    assert on > 30 and gn == on and np.array_equal(gm, om)
+    # identical key frames with every point good; one side empty
+    ones = np.ones(len(s["k1"]), np.uint8)
+    om, on = O.search_by_bow_keyframes(s["k1"], s["d1"], s["n1"], ones, s["k1"], s["d1"], s["n1"], ones, ratio, ori)
+    gm, gn = orbhip.SearchByBoWKeyFrames(ex, s["k1"], s["d1"], s["n1"], ones, s["k1"], s["d1"], s["n1"], ones, ratio, ori)
+    assert gn == on and np.array_equal(gm, om)
+    gm, gn = orbhip.SearchByBoWKeyFrames(ex, s["k1"], s["d1"], s["n1"], ones, s["k2"][:0], s["d2"][:0], s["n2"][:0], f2[:0], ratio, ori)
+    assert gn == 0 and np.all(gm == -1) and len(gm) == len(s["k1"])

@@ -951,18 +951,24 @@ __device__ __forceinline__ void mb_sort(unsigned long long* a, int n) {
     }
 }
 
+// KFKF: ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (reference
+// src/ORBmatcher.cc:519-652, loop detection): side 2 is a key frame too, only its features with a
+// good map point (flags2) are candidates, the acceptance test is bestDist1 < TH_LOW, and the result
+// is indexed by the feature of side 1 (match[i1] = feature of side 2).
+template <bool KFKF>
 __global__ __launch_bounds__(MP_THREADS) void k_search_bow(const GridKp* __restrict__ kp1, const uint8_t* __restrict__ desc1,
                                                            const uint32_t* __restrict__ node1, const uint8_t* __restrict__ flags1,
                                                            const int* __restrict__ cnt1, const GridKp* __restrict__ kp2,
                                                            const uint8_t* __restrict__ desc2, const uint32_t* __restrict__ node2,
+                                                           const uint8_t* __restrict__ flags2,
                                                            const int* __restrict__ cnt2, int cap, int npad, float nnratio,
                                                            int check_orientation, int* __restrict__ match2, int* __restrict__ nmatches_out) {
     extern __shared__ __align__(16) uint8_t mb_smem[];
     unsigned long long* A = reinterpret_cast<unsigned long long*>(mb_smem);   // key frame: node << 16 | index, sorted
     unsigned long long* B = A + npad;                                          // frame: the same
     uint32_t* run_start = reinterpret_cast<uint32_t*>(B + npad);              // scan of the run heads, then first position of every run
-    uint8_t* taken2 = reinterpret_cast<uint8_t*>(run_start + npad);           // frame feature already holds a match
-    uint8_t* bin2 = taken2 + npad;                                            // rotation bin of that match, 0xFF = none
+    uint8_t* taken2 = reinterpret_cast<uint8_t*>(run_start + npad);           // frame feature already holds a match (KFKF: or has no good map point)
+    uint8_t* bin2 = taken2 + npad;                                            // rotation bin of the match of the output slot, 0xFF = none
     __shared__ uint32_t s_tmp[MP_WAVES];
     __shared__ int s_hist[MT_HISTO];
     __shared__ int s_count[2];                                                // matches made, matches removed
@@ -975,9 +981,9 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_bow(const GridKp* __restr
         const uint32_t na = i < n1 ? node1[o + i] : MB_NONE_NODE, nb = i < n2 ? node2[o + i] : MB_NONE_NODE;
         A[i] = ((unsigned long long)na << 16) | (unsigned)i;
         B[i] = ((unsigned long long)nb << 16) | (unsigned)i;
-        taken2[i] = 0;
+        taken2[i] = (uint8_t)(KFKF ? (i < n2 ? !(flags2[o + i] & 1) : 1) : 0);   // src/ORBmatcher.cc:571-577
         bin2[i] = 0xFF;
-        if (i < n2) m2[i] = -1;
+        if (i < (KFKF ? n1 : n2)) m2[i] = -1;
     }
     if (tid < MT_HISTO) s_hist[tid] = 0;
     if (tid < 2) s_count[tid] = 0;
@@ -1049,18 +1055,19 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_bow(const GridKp* __restr
             for (int sh = 32; sh > 0; sh >>= 1) other = min(other, (uint32_t)__shfl_xor((int)other, sh, 64));
             const int bestDist1 = (int)(wbest >> 16);
             const int bestDist2 = other == 0x7FFFFFFFu ? 256 : (int)other;
-            if (bestDist1 <= MT_TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {   // src/ORBmatcher.cc:225-227
+            if ((KFKF ? bestDist1 < MT_TH_LOW : bestDist1 <= MT_TH_LOW) && (float)bestDist1 < nnratio * (float)bestDist2) {   // src/ORBmatcher.cc:225-227, 595-597
                 const int i2 = (int)(B[fs + (int)(wbest & 0xFFFF)] & 0xFFFF);
                 made++;
                 if (lane == 0) {
                     taken2[i2] = 1;
-                    m2[i2] = i1;
+                    const int slot = KFKF ? i1 : i2;            // vpMatches12[idx1] / vpMapPointMatches[bestIdxF]
+                    m2[slot] = KFKF ? i2 : i1;
                     if (check_orientation) {
                         float rot = kp1[o + i1].angle - kp2[o + i2].angle;
                         if (rot < 0.0f) rot += 360.0f;
                         int bin = (int)roundf(rot * (1.0f / MT_HISTO));
                         if (bin == MT_HISTO) bin = 0;
-                        bin2[i2] = (uint8_t)bin;
+                        bin2[slot] = (uint8_t)bin;
                         atomicAdd(&s_hist[bin], 1);
                     }
                 }
@@ -1080,9 +1087,9 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_bow(const GridKp* __restr
         }
         if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
         else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
-        for (int i = tid; i < n2; i += MP_THREADS) {
+        for (int i = tid; i < (KFKF ? n1 : n2); i += MP_THREADS) {
             const int b = bin2[i];
-            if (b != 0xFF && b != ind1 && b != ind2 && b != ind3) { m2[i] = -1; bad++; }   // src/ORBmatcher.cc:272-281
+            if (b != 0xFF && b != ind1 && b != ind2 && b != ind3) { m2[i] = -1; bad++; }   // src/ORBmatcher.cc:272-281, 639-648
         }
     }
 #pragma unroll

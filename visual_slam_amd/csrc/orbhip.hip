@@ -1353,13 +1353,13 @@ int orbhip_search_by_projection_keyframe(orbhip_extractor* e, const orbhip_keypo
     return ORBHIP_OK;
 }
 
-int orbhip_search_by_bow_batch_device(orbhip_extractor* e, int nframes, int cap, const orbhip_keypoint* d_kp_kf,
-                                      const uint8_t* d_desc_kf, const uint32_t* d_node_kf, const uint8_t* d_flags_kf,
-                                      const int* d_cnt_kf, const orbhip_keypoint* d_kp_f, const uint8_t* d_desc_f,
-                                      const uint32_t* d_node_f, const int* d_cnt_f, float nnratio, int check_orientation,
-                                      int* d_match_f, int* d_nmatches, void* stream) {
-    if (!e || nframes < 1 || cap < 1 || !d_kp_kf || !d_desc_kf || !d_node_kf || !d_flags_kf || !d_cnt_kf || !d_kp_f || !d_desc_f ||
-        !d_node_f || !d_cnt_f || !d_match_f || !d_nmatches)
+static int search_by_bow_launch(orbhip_extractor* e, bool kfkf, int nframes, int cap, const orbhip_keypoint* d_kp1,
+                                const uint8_t* d_desc1, const uint32_t* d_node1, const uint8_t* d_flags1, const int* d_cnt1,
+                                const orbhip_keypoint* d_kp2, const uint8_t* d_desc2, const uint32_t* d_node2,
+                                const uint8_t* d_flags2, const int* d_cnt2, float nnratio, int check_orientation,
+                                int* d_match, int* d_nmatches, void* stream) {
+    if (!e || nframes < 1 || cap < 1 || !d_kp1 || !d_desc1 || !d_node1 || !d_flags1 || !d_cnt1 || !d_kp2 || !d_desc2 ||
+        !d_node2 || !d_cnt2 || !d_match || !d_nmatches || (kfkf && !d_flags2))
         return ORBHIP_ERR_ARG;
     if (cap > 4096) { e->err = "too many keypoints per frame for the on-chip sort of the bag-of-words matcher"; return ORBHIP_ERR_CAPACITY; }
     int npad = 64;
@@ -1367,28 +1367,53 @@ int orbhip_search_by_bow_batch_device(orbhip_extractor* e, int nframes, int cap,
     const size_t lds = (size_t)MB_LDS_PER_SLOT * npad;
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
-    if (lds > 40 * 1024)
-        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_bow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_search_bow, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const GridKp*>(d_kp_kf), d_desc_kf, d_node_kf,
-                       d_flags_kf, d_cnt_kf, reinterpret_cast<const GridKp*>(d_kp_f), d_desc_f, d_node_f, d_cnt_f, cap, npad, nnratio,
-                       check_orientation, d_match_f, d_nmatches);
+    const void* fn = kfkf ? reinterpret_cast<const void*>(k_search_bow<true>) : reinterpret_cast<const void*>(k_search_bow<false>);
+    if (lds > 40 * 1024) HIP_TRY(e, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (kfkf)
+        hipLaunchKernelGGL(k_search_bow<true>, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const GridKp*>(d_kp1), d_desc1,
+                           d_node1, d_flags1, d_cnt1, reinterpret_cast<const GridKp*>(d_kp2), d_desc2, d_node2, d_flags2, d_cnt2, cap, npad,
+                           nnratio, check_orientation, d_match, d_nmatches);
+    else
+        hipLaunchKernelGGL(k_search_bow<false>, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const GridKp*>(d_kp1), d_desc1,
+                           d_node1, d_flags1, d_cnt1, reinterpret_cast<const GridKp*>(d_kp2), d_desc2, d_node2, d_flags2, d_cnt2, cap, npad,
+                           nnratio, check_orientation, d_match, d_nmatches);
     HIP_TRY(e, hipGetLastError());
     return ORBHIP_OK;
 }
 
-int orbhip_search_by_bow(orbhip_extractor* e, const orbhip_keypoint* kp_kf, const uint8_t* desc_kf, const uint32_t* node_kf,
-                         const uint8_t* flags_kf, int n1, const orbhip_keypoint* kp_f, const uint8_t* desc_f,
-                         const uint32_t* node_f, int n2, float nnratio, int check_orientation, int* match_f, int* nmatches) {
+int orbhip_search_by_bow_batch_device(orbhip_extractor* e, int nframes, int cap, const orbhip_keypoint* d_kp_kf,
+                                      const uint8_t* d_desc_kf, const uint32_t* d_node_kf, const uint8_t* d_flags_kf,
+                                      const int* d_cnt_kf, const orbhip_keypoint* d_kp_f, const uint8_t* d_desc_f,
+                                      const uint32_t* d_node_f, const int* d_cnt_f, float nnratio, int check_orientation,
+                                      int* d_match_f, int* d_nmatches, void* stream) {
+    return search_by_bow_launch(e, false, nframes, cap, d_kp_kf, d_desc_kf, d_node_kf, d_flags_kf, d_cnt_kf, d_kp_f, d_desc_f, d_node_f,
+                                nullptr, d_cnt_f, nnratio, check_orientation, d_match_f, d_nmatches, stream);
+}
+
+int orbhip_search_by_bow_keyframes_batch_device(orbhip_extractor* e, int nframes, int cap, const orbhip_keypoint* d_kp1,
+                                                const uint8_t* d_desc1, const uint32_t* d_node1, const uint8_t* d_flags1,
+                                                const int* d_cnt1, const orbhip_keypoint* d_kp2, const uint8_t* d_desc2,
+                                                const uint32_t* d_node2, const uint8_t* d_flags2, const int* d_cnt2, float nnratio,
+                                                int check_orientation, int* d_match12, int* d_nmatches, void* stream) {
+    return search_by_bow_launch(e, true, nframes, cap, d_kp1, d_desc1, d_node1, d_flags1, d_cnt1, d_kp2, d_desc2, d_node2, d_flags2,
+                                d_cnt2, nnratio, check_orientation, d_match12, d_nmatches, stream);
+}
+
+static int search_by_bow_host(orbhip_extractor* e, bool kfkf, const orbhip_keypoint* kp1, const uint8_t* desc1, const uint32_t* node1,
+                              const uint8_t* flags1, int n1, const orbhip_keypoint* kp2, const uint8_t* desc2,
+                              const uint32_t* node2, const uint8_t* flags2, int n2, float nnratio, int check_orientation,
+                              int* match, int* nmatches) {
     if (!e || n1 < 0 || n2 < 0 || !nmatches) return ORBHIP_ERR_ARG;
-    if (n2 > 0 && !match_f) return ORBHIP_ERR_ARG;
-    for (int i = 0; i < n2; i++) match_f[i] = -1;
+    const int nout = kfkf ? n1 : n2;                           // the result is indexed by side 1 for two key frames, by the frame otherwise
+    if (nout > 0 && !match) return ORBHIP_ERR_ARG;
+    for (int i = 0; i < nout; i++) match[i] = -1;
     if (n1 == 0 || n2 == 0) { *nmatches = 0; return ORBHIP_OK; }
-    if (!kp_kf || !desc_kf || !node_kf || !flags_kf || !kp_f || !desc_f || !node_f) return ORBHIP_ERR_ARG;
+    if (!kp1 || !desc1 || !node1 || !flags1 || !kp2 || !desc2 || !node2 || (kfkf && !flags2)) return ORBHIP_ERR_ARG;
     HIP_TRY(e, hipSetDevice(e->device));
     const int cap = std::max(n1, n2);
     auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
     const size_t kpb = up((size_t)cap * sizeof(orbhip_keypoint)), db = up((size_t)cap * 32), nb = up((size_t)cap * 4), fb = up((size_t)cap);
-    const size_t need = 64 + 2 * kpb + 2 * db + 3 * nb + fb;
+    const size_t need = 64 + 2 * kpb + 2 * db + 3 * nb + 2 * fb;
     if (need > e->d_st_tmp_bytes) {
         HIP_TRY(e, hipDeviceSynchronize());
         dfree(e->d_st_tmp);
@@ -1404,24 +1429,41 @@ int orbhip_search_by_bow(orbhip_extractor* e, const orbhip_keypoint* kp_kf, cons
     uint32_t* d_n1 = reinterpret_cast<uint32_t*>(p); p += nb;
     uint32_t* d_n2 = reinterpret_cast<uint32_t*>(p); p += nb;
     int* d_m = reinterpret_cast<int*>(p); p += nb;
-    uint8_t* d_f = p;
+    uint8_t* d_f1 = p; p += fb;
+    uint8_t* d_f2 = p;
     const int cnt[3] = {n1, n2, 0};
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     HIP_TRY(e, hipMemcpy(d_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_k1, kp_kf, (size_t)n1 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_d1, desc_kf, (size_t)n1 * 32, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_n1, node_kf, (size_t)n1 * 4, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_f, flags_kf, (size_t)n1, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_k2, kp_f, (size_t)n2 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_d2, desc_f, (size_t)n2 * 32, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_n2, node_f, (size_t)n2 * 4, hipMemcpyHostToDevice));
-    int rc = orbhip_search_by_bow_batch_device(e, 1, cap, d_k1, d_d1, d_n1, d_f, d_cnt, d_k2, d_d2, d_n2, d_cnt + 1, nnratio,
-                                               check_orientation, d_m, d_cnt + 2, nullptr);
+    HIP_TRY(e, hipMemcpy(d_k1, kp1, (size_t)n1 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_d1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_n1, node1, (size_t)n1 * 4, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_f1, flags1, (size_t)n1, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_k2, kp2, (size_t)n2 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_d2, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_n2, node2, (size_t)n2 * 4, hipMemcpyHostToDevice));
+    if (kfkf) HIP_TRY(e, hipMemcpy(d_f2, flags2, (size_t)n2, hipMemcpyHostToDevice));
+    int rc = search_by_bow_launch(e, kfkf, 1, cap, d_k1, d_d1, d_n1, d_f1, d_cnt, d_k2, d_d2, d_n2, kfkf ? d_f2 : nullptr, d_cnt + 1,
+                                  nnratio, check_orientation, d_m, d_cnt + 2, nullptr);
     if (rc) return rc;
     HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipMemcpy(match_f, d_m, (size_t)n2 * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(match, d_m, (size_t)nout * sizeof(int), hipMemcpyDeviceToHost));
     HIP_TRY(e, hipMemcpy(nmatches, d_cnt + 2, sizeof(int), hipMemcpyDeviceToHost));
     return ORBHIP_OK;
+}
+
+int orbhip_search_by_bow(orbhip_extractor* e, const orbhip_keypoint* kp_kf, const uint8_t* desc_kf, const uint32_t* node_kf,
+                         const uint8_t* flags_kf, int n1, const orbhip_keypoint* kp_f, const uint8_t* desc_f,
+                         const uint32_t* node_f, int n2, float nnratio, int check_orientation, int* match_f, int* nmatches) {
+    return search_by_bow_host(e, false, kp_kf, desc_kf, node_kf, flags_kf, n1, kp_f, desc_f, node_f, nullptr, n2, nnratio,
+                              check_orientation, match_f, nmatches);
+}
+
+int orbhip_search_by_bow_keyframes(orbhip_extractor* e, const orbhip_keypoint* kp1, const uint8_t* desc1, const uint32_t* node1,
+                                   const uint8_t* flags1, int n1, const orbhip_keypoint* kp2, const uint8_t* desc2,
+                                   const uint32_t* node2, const uint8_t* flags2, int n2, float nnratio, int check_orientation,
+                                   int* match12, int* nmatches) {
+    return search_by_bow_host(e, true, kp1, desc1, node1, flags1, n1, kp2, desc2, node2, flags2, n2, nnratio, check_orientation,
+                              match12, nmatches);
 }
 
 int orbhip_search_map_points_batch_device(orbhip_extractor* e, int nframes, int cap_mp, const orbhip_track_point* d_mp,

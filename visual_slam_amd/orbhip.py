@@ -40,6 +40,7 @@ EXPORTS = [
     "orbhip_is_in_frustum", "orbhip_is_in_frustum_batch_device", "orbhip_debug_logf",
     "orbhip_search_by_projection_keyframe", "orbhip_search_by_projection_keyframe_batch_device",
     "orbhip_search_by_bow", "orbhip_search_by_bow_batch_device",
+    "orbhip_search_by_bow_keyframes", "orbhip_search_by_bow_keyframes_batch_device",
 ]
 
 
@@ -111,6 +112,8 @@ def lib():
         L.orbhip_search_by_projection_keyframe_batch_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 12 + [C.c_int, vp, vp, vp]
         L.orbhip_search_by_bow.argtypes = [vp] * 5 + [C.c_int] + [vp] * 3 + [C.c_int, C.c_float, C.c_int, vp, ip]
         L.orbhip_search_by_bow_batch_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 9 + [C.c_float, C.c_int, vp, vp, vp]
+        L.orbhip_search_by_bow_keyframes.argtypes = [vp] * 5 + [C.c_int] + [vp] * 4 + [C.c_int, C.c_float, C.c_int, vp, ip]
+        L.orbhip_search_by_bow_keyframes_batch_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 10 + [C.c_float, C.c_int, vp, vp, vp]
         L.orbhip_debug_logf.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
         L.orbhip_is_in_frustum.argtypes = [vp, vp, C.c_int, vp, vp, C.c_float, vp, ip]
         L.orbhip_is_in_frustum_batch_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_float, vp, vp, vp]
@@ -241,6 +244,20 @@ def SearchByBoW(ex, kp_kf, desc_kf, node_kf, flags_kf, kp_f, desc_f, node_f, nnr
     ex._check(lib().orbhip_search_by_bow(ex._h, _ptr(kp_kf), _ptr(d1), _ptr(n1), _ptr(fl), len(kp_kf), _ptr(kp_f), _ptr(d2), _ptr(n2),
                                          len(kp_f), float(nnratio), int(bool(check_orientation)), _ptr(m), C.byref(n)))
     return m[:len(kp_f)], n.value
+
+
+def SearchByBoWKeyFrames(ex, kp1, desc1, node1, flags1, kp2, desc2, node2, flags2, nnratio=0.75, check_orientation=True):
+    """ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (reference src/ORBmatcher.cc:519-652) on the device.
+    Returns (match12, nmatches): match12[i1] = feature of key frame 2 whose map point vpMatches12[i1] receives, or -1."""
+    kp1 = np.ascontiguousarray(kp1, KP_DTYPE); kp2 = np.ascontiguousarray(kp2, KP_DTYPE)
+    d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+    n1 = np.ascontiguousarray(node1, np.uint32); n2 = np.ascontiguousarray(node2, np.uint32)
+    f1 = np.ascontiguousarray(flags1, np.uint8); f2 = np.ascontiguousarray(flags2, np.uint8)
+    m = np.full(max(len(kp1), 1), -1, np.int32)
+    n = C.c_int(0)
+    ex._check(lib().orbhip_search_by_bow_keyframes(ex._h, _ptr(kp1), _ptr(d1), _ptr(n1), _ptr(f1), len(kp1), _ptr(kp2), _ptr(d2), _ptr(n2),
+                                                   _ptr(f2), len(kp2), float(nnratio), int(bool(check_orientation)), _ptr(m), C.byref(n)))
+    return m[:len(kp1)], n.value
 
 
 def search_by_bow_batch_device(ex, nframes, cap, d_kp_kf, d_desc_kf, d_node_kf, d_flags_kf, d_cnt_kf, d_kp_f, d_desc_f, d_node_f,
