@@ -301,6 +301,27 @@ int orbhip_search_by_projection_keyframe(orbhip_extractor* e, const orbhip_keypo
                                          const float* Tcw, const orbhip_projection_params* prm, int orb_dist,
                                          int* match_cur, int* nmatches);
 
+/* ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints,
+ * vector<MapPoint*>& vpMatched, int th) (src/ORBmatcher.cc:287-400, loop closing) on plain arrays.
+ * Per candidate map point: GetWorldPos(), GetNormal(), {mfMinDistance, mfMaxDistance}, flags bit 0 =
+ * "not bad and not already in vpMatched", GetDescriptor(). Key frame: mvKeysUn (x, y, octave),
+ * descriptors, occupied = 1 where vpMatched[idx] is not NULL on entry (NULL: none). d_Tcw: per frame the
+ * 12 floats orbhip_decompose_sim3 makes of Scw (rotation and translation with the scale divided out,
+ * src/ORBmatcher.cc:296-299); the host-array call takes Scw itself (3 x 4, row-major: sR | t... laid out
+ * as R row-major then t, like the poses elsewhere). prm: camera, bounds, th (mbf and check_orientation
+ * are not read). d_match_kf[idx] = index of the map point this call put into vpMatched[idx], else -1. */
+int orbhip_decompose_sim3(const float* Scw, float* Tcw);
+int orbhip_search_by_projection_sim3_batch_device(orbhip_extractor* e, int nframes, int cap, const float* d_world,
+                                                  const float* d_normal, const float* d_dist_range, const uint8_t* d_flags,
+                                                  const uint8_t* d_desc, const int* d_cnt_pts, const orbhip_keypoint* d_kp_kf,
+                                                  const uint8_t* d_desc_kf, const uint8_t* d_occupied_kf, const int* d_cnt_kf,
+                                                  const float* d_Tcw, const orbhip_projection_params* prm, int* d_match_kf,
+                                                  int* d_nmatches, void* stream);
+int orbhip_search_by_projection_sim3(orbhip_extractor* e, const float* world, const float* normal, const float* dist_range,
+                                     const uint8_t* flags, const uint8_t* desc, int n1, const orbhip_keypoint* kp_kf,
+                                     const uint8_t* desc_kf, const uint8_t* occupied_kf, int n2, const float* Scw,
+                                     const orbhip_projection_params* prm, int* match_kf, int* nmatches);
+
 /* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (src/ORBmatcher.cc:156-285;
  * Tracking::TrackReferenceKeyFrame and relocalisation) on plain arrays. The DBoW2 feature vectors
  * (pKF->mFeatVec, F.mFeatVec: vocabulary node -> feature indices) arrive as one node id per feature

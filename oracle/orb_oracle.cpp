@@ -1401,6 +1401,132 @@ int orbo_search_by_projection_keyframe(const orbo_keypoint* k_kf, const float* w
     return nmatches;
 }
 
+/* ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints,
+ * vector<MapPoint*>& vpMatched, int th) (src/ORBmatcher.cc:287-400, loop closing) with
+ * KeyFrame::GetFeaturesInArea and IsInImage (src/KeyFrame.cc:569-613) on plain arrays. Candidate map
+ * points, n1: world = GetWorldPos(), normal = GetNormal(), dist_range = {mfMinDistance, mfMaxDistance},
+ * flags bit 0 = "not bad and not in spAlreadyFound", desc = GetDescriptor(). Key frame, n2 keypoints:
+ * k_kf = mvKeysUn, desc_kf, occupied_kf[idx] = "vpMatched[idx] is not NULL on entry" (NULL: none).
+ * Scw: 12 floats, the upper 3 x 4 of the similarity as sR row-major (9) then t (3). match_kf[idx] =
+ * index of the map point this call stored in vpMatched[idx], else -1. Returns nmatches.
+ * Mat arithmetic as OpenCV performs it for CV_32F: row.dot(row) in double, Mat / scalar = every
+ * element times the float value of 1 / scalar, Rcw * p + tcw through the small-matrix product,
+ * -Rcw.t() * tcw through the general one (double accumulation), norm and dot of 3 elements in double. */
+int orbo_search_by_projection_sim3(const float* world, const float* normal, const float* dist_range, const uint8_t* flags,
+                                   const uint8_t* desc, int n1, const orbo_keypoint* k_kf, const uint8_t* desc_kf,
+                                   const uint8_t* occupied_kf, int n2, const float* Scw, const float* cam, const float* bounds,
+                                   const float* scale_factors, float scale_factor, int nlevels, int th, int* match_kf) {
+    const int COLS = 64, ROWS = 48, TH_LOW = 50;
+    const float mnMinX = bounds[0], mnMaxX = bounds[1], mnMinY = bounds[2], mnMaxY = bounds[3];
+    const float wInv = static_cast<float>(COLS) / (mnMaxX - mnMinX);
+    const float hInv = static_cast<float>(ROWS) / (mnMaxY - mnMinY);
+    const float fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3];
+    const float mfLogScaleFactor = std::log(scale_factor);
+    /* decompose Scw */
+    const float scw = (float)std::sqrt((double)Scw[0] * Scw[0] + (double)Scw[1] * Scw[1] + (double)Scw[2] * Scw[2]);
+    const float inv_scw = (float)(1.0 / scw);
+    float Rcw[9], tcw[3], Ow[3];
+    for (int i = 0; i < 9; i++) Rcw[i] = Scw[i] * inv_scw;
+    for (int i = 0; i < 3; i++) tcw[i] = Scw[9 + i] * inv_scw;
+    for (int r = 0; r < 3; r++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)Rcw[3 * k + r] * (double)tcw[k];
+        Ow[r] = (float)(-s);
+    }
+    std::vector<std::vector<size_t>> mGrid((size_t)COLS * ROWS);
+    for (int i = 0; i < n2; i++) {
+        const int posX = (int)std::round((k_kf[i].x - mnMinX) * wInv);
+        const int posY = (int)std::round((k_kf[i].y - mnMinY) * hInv);
+        if (posX < 0 || posX >= COLS || posY < 0 || posY >= ROWS) continue;
+        mGrid[(size_t)posX * ROWS + posY].push_back((size_t)i);
+    }
+    auto GetFeaturesInArea = [&](float x, float y, float r) {  /* src/KeyFrame.cc:569-608 */
+        std::vector<size_t> vIndices;
+        const int nMinCellX = std::max(0, (int)std::floor((x - mnMinX - r) * wInv));
+        if (nMinCellX >= COLS) return vIndices;
+        const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((x - mnMinX + r) * wInv));
+        if (nMaxCellX < 0) return vIndices;
+        const int nMinCellY = std::max(0, (int)std::floor((y - mnMinY - r) * hInv));
+        if (nMinCellY >= ROWS) return vIndices;
+        const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((y - mnMinY + r) * hInv));
+        if (nMaxCellY < 0) return vIndices;
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                const std::vector<size_t>& vCell = mGrid[(size_t)ix * ROWS + iy];
+                for (size_t j = 0; j < vCell.size(); j++) {
+                    const orbo_keypoint& kpUn = k_kf[vCell[j]];
+                    const float distx = kpUn.x - x, disty = kpUn.y - y;
+                    if (std::fabs(distx) < r && std::fabs(disty) < r) vIndices.push_back(vCell[j]);
+                }
+            }
+        return vIndices;
+    };
+    auto DescriptorDistance = [](const uint8_t* a, const uint8_t* b) {   /* src/ORBmatcher.cc:1611-1627 */
+        int dist = 0;
+        for (int i = 0; i < 8; i++) {
+            uint32_t pa, pb;
+            std::memcpy(&pa, a + 4 * i, 4); std::memcpy(&pb, b + 4 * i, 4);
+            unsigned int v = pa ^ pb;
+            v = v - ((v >> 1) & 0x55555555);
+            v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+            dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+        }
+        return dist;
+    };
+    std::vector<char> holds((size_t)n2);                       /* vpMatched[idx] != NULL */
+    for (int i = 0; i < n2; i++) { holds[i] = occupied_kf && occupied_kf[i]; match_kf[i] = -1; }
+    int nmatches = 0;
+    for (int iMP = 0; iMP < n1; iMP++) {
+        if (!(flags[iMP] & 1)) continue;
+        const float* p3Dw = world + 3 * (size_t)iMP;
+        float p3Dc[3];
+        for (int r = 0; r < 3; r++) {
+            const float t = Rcw[3 * r] * p3Dw[0] + Rcw[3 * r + 1] * p3Dw[1] + Rcw[3 * r + 2] * p3Dw[2];
+            p3Dc[r] = (float)((double)t * 1.0 + (double)tcw[r] * 1.0);
+        }
+        if (p3Dc[2] < 0.0) continue;
+        const float invz = 1 / p3Dc[2];
+        const float x = p3Dc[0] * invz;
+        const float y = p3Dc[1] * invz;
+        const float u = fx * x + cx;
+        const float v = fy * y + cy;
+        if (!(u >= mnMinX && u < mnMaxX && v >= mnMinY && v < mnMaxY)) continue;   /* KeyFrame::IsInImage */
+        const float maxDistance = 1.2f * dist_range[2 * iMP + 1];
+        const float minDistance = 0.8f * dist_range[2 * iMP];
+        const float PO[3] = {p3Dw[0] - Ow[0], p3Dw[1] - Ow[1], p3Dw[2] - Ow[2]};
+        double nrm = 0;
+        for (int k = 0; k < 3; k++) { const double e = PO[k]; nrm += e * e; }
+        const float dist = (float)std::sqrt(nrm);
+        if (dist < minDistance || dist > maxDistance) continue;
+        double dot = 0;
+        for (int k = 0; k < 3; k++) dot += (double)PO[k] * normal[3 * (size_t)iMP + k];
+        if (dot < 0.5 * dist) continue;
+        const float ratio = dist_range[2 * iMP + 1] / dist;    /* MapPoint::PredictScale */
+        const float c = std::ceil(std::log(ratio) / mfLogScaleFactor);
+        int nPredictedLevel = (c >= -2147483648.0f && c < 2147483648.0f) ? (int)c : (-2147483647 - 1);
+        if (nPredictedLevel < 0) nPredictedLevel = 0;
+        else if (nPredictedLevel >= nlevels) nPredictedLevel = nlevels - 1;
+        const float radius = th * scale_factors[nPredictedLevel];
+        const std::vector<size_t> vIndices = GetFeaturesInArea(u, v, radius);
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = desc + 32 * (size_t)iMP;
+        int bestDist = 256, bestIdx = -1;
+        for (size_t idx : vIndices) {
+            if (holds[idx]) continue;
+            const int kpLevel = k_kf[idx].octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            const int d = DescriptorDistance(dMP, desc_kf + 32 * idx);
+            if (d < bestDist) { bestDist = d; bestIdx = (int)idx; }
+        }
+        if (bestDist <= TH_LOW) {
+            holds[bestIdx] = 1;
+            match_kf[bestIdx] = iMP;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
+
 /* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (src/ORBmatcher.cc:156-285)
  * on plain arrays. node_kf / node_f: the vocabulary node of every feature (0xFFFFFFFF: none), from
  * which the DBoW2 feature vectors (std::map node -> indices in ascending order, as

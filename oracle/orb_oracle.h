@@ -125,6 +125,11 @@ int orbo_search_by_projection_keyframe(const orbo_keypoint* k_kf, const float* w
                                        const uint8_t* desc_cur, const uint8_t* occupied_cur, int n2, const float* Tcw,
                                        const float* cam, const float* bounds, const float* scale_factors, float scale_factor,
                                        int nlevels, float th, int ORBdist, int mbCheckOrientation, int* match_cur);
+/* ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, vpPoints, vpMatched, th) (src/ORBmatcher.cc:287-400). */
+int orbo_search_by_projection_sim3(const float* world, const float* normal, const float* dist_range, const uint8_t* flags,
+                                   const uint8_t* desc, int n1, const orbo_keypoint* k_kf, const uint8_t* desc_kf,
+                                   const uint8_t* occupied_kf, int n2, const float* Scw, const float* cam, const float* bounds,
+                                   const float* scale_factors, float scale_factor, int nlevels, int th, int* match_kf);
 /* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (src/ORBmatcher.cc:156-285). */
 int orbo_search_by_bow(const orbo_keypoint* k_kf, const uint8_t* desc_kf, const uint32_t* node_kf, const uint8_t* flags_kf, int n1,
                        const orbo_keypoint* k_f, const uint8_t* desc_f, const uint32_t* node_f, int n2, float mfNNratio,

@@ -91,6 +91,8 @@ def lib():
             [C.c_float, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
         L.orbo_search_by_bow.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.orbo_search_by_bow_keyframes.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.orbo_search_by_projection_sim3.argtypes = [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4 + \
+            [C.c_float, C.c_int, C.c_int, C.c_void_p]
         L.orbo_libm_logf.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orbo_libm_sincos.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orbo_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
@@ -439,3 +441,22 @@ def search_by_bow_keyframes(kp1, desc1, node1, flags1, kp2, desc2, node2, flags2
     n = lib().orbo_search_by_bow_keyframes(_ptr(kp1), _ptr(d1), _ptr(n1), _ptr(f1), len(kp1), _ptr(kp2), _ptr(d2), _ptr(n2), _ptr(f2),
                                            len(kp2), float(nnratio), int(bool(check_orientation)), _ptr(m))
     return m[:len(kp1)], n
+
+
+def search_by_projection_sim3(world, normal, dist_range, flags, desc, kp_kf, desc_kf, occupied_kf, Scw, cam4, bounds, scale_factors,
+                              scale_factor, th):
+    """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th): returns (match_kf, nmatches)."""
+    kp_kf = np.ascontiguousarray(kp_kf, KP_DTYPE)
+    w = np.ascontiguousarray(world, np.float32).reshape(-1, 3); nr = np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
+    rg = np.ascontiguousarray(dist_range, np.float32).reshape(-1, 2)
+    fl = np.ascontiguousarray(flags, np.uint8)
+    d1 = np.ascontiguousarray(desc, np.uint8); d2 = np.ascontiguousarray(desc_kf, np.uint8)
+    oc = None if occupied_kf is None else np.ascontiguousarray(occupied_kf, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    m = np.full(max(len(kp_kf), 1), -1, np.int32)
+    n = lib().orbo_search_by_projection_sim3(_ptr(w), _ptr(nr), _ptr(rg), _ptr(fl), _ptr(d1), len(w), _ptr(kp_kf), _ptr(d2),
+                                             None if oc is None else _ptr(oc), len(kp_kf),
+                                             _ptr(np.ascontiguousarray(Scw, np.float32).reshape(12)),
+                                             _ptr(np.ascontiguousarray(cam4, np.float32)), _ptr(np.ascontiguousarray(bounds, np.float32)),
+                                             _ptr(sf), float(np.float32(scale_factor)), len(sf), int(th), _ptr(m))
+    return m[:len(kp_kf)], n

@@ -210,3 +210,68 @@ def test_hip_keyframe_projection_matches_oracle(cam, w, h, dx, dy, th, orb_dist,
         gm, gn = orbhip.SearchByProjectionKeyFrame(ex, s["u1"], s["world"], s["range"], s["flags"], s["d1"], s["u2"], s["d2"], None,
                                                    s["Tcw"], s["cam4"], s["bounds"], th, orb_dist, ori)
         assert gn == on and np.array_equal(gm, om)
+
+
+# ---- the loop-closing variant: SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (reference src/ORBmatcher.cc:287-400)
+
+def sim3_scenario(w, h, index, dx, dy, cam, scale=1.3, seed=23):
+    s = keyframe_scenario(w, h, index, dx, dy, cam, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    n1 = len(s["u1"])
+    Ow = -s["Tcw"][9:12]                                                     # R = I
+    view = s["world"] - Ow
+    nrm = view / np.linalg.norm(view, axis=1, keepdims=True) + rng.normal(0, 0.5, (n1, 3))   # some beyond 60 degrees
+    s["normal"] = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    s["Scw"] = (s["Tcw"].astype(np.float64) * scale).astype(np.float32)        # s [R | t]
+    return s
+
+
+def run_oracle_sim3(s, th, occupied=True):
+    from oracle import orb_oracle as O
+    return O.search_by_projection_sim3(s["world"], s["normal"], s["range"], s["flags"], s["d1"], s["u2"], s["d2"],
+                                       s["occupied"] if occupied else None, s["Scw"], s["cam4"], s["bounds"], s["sf"], 1.2, th)
+
+
+def test_oracle_sim3_projection_properties():
+    s = sim3_scenario(640, 480, 77, 7, -4, KITTI)
+    m, n = run_oracle_sim3(s, 10)
+    got = m >= 0
+    assert n == got.sum() and n > 100
+    assert not np.any(got & (s["occupied"] != 0))
+    # the viewing direction of every matched point lies within 60 degrees of its normal
+    view = s["world"][m[got]] + s["Tcw"][9:12]
+    cosv = np.sum(view * s["normal"][m[got]], axis=1) / np.linalg.norm(view, axis=1)
+    assert np.all(cosv >= 0.5 - 1e-4)
+    # the scale of the similarity is divided out: another scale, the same matches
+    s2 = dict(s, Scw=(s["Tcw"].astype(np.float64) * 0.5).astype(np.float32))   # a power of two: the division is exact
+    m2, n2 = run_oracle_sim3(s2, 10)
+    s1 = dict(s, Scw=s["Tcw"])
+    m1, n1 = run_oracle_sim3(s1, 10)
+    assert n2 == n1 and np.array_equal(m2, m1)
+    # octaves: [level - 1, level] of the predicted level, so never above it
+    assert n1 > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cam,w,h,dx,dy,th,scale", [
+    (KITTI, 1241, 376, 9, 3, 10, 1.3),
+    (TUM1, 640, 480, -11, 8, 4, 0.77),
+    (KITTI, 752, 480, 14, -5, 10, 1.0),
+])
+def test_hip_sim3_projection_matches_oracle(cam, w, h, dx, dy, th, scale):
+    from visual_slam_amd import orbhip
+    s = sim3_scenario(w, h, 78, dx, dy, cam, scale=scale)
+    om, on = run_oracle_sim3(s, th)
+    ex = orbhip.ORBextractor(2000, 1.2, 8, 20, 7)
+    gm, gn = orbhip.SearchByProjectionSim3(ex, s["world"], s["normal"], s["range"], s["flags"], s["d1"], s["u2"], s["d2"], s["occupied"],
+                                           s["Scw"], s["cam4"], s["bounds"], th)
+    assert on > 40 and gn == on
+    assert np.array_equal(gm, om)
+    # contested: every point twice, nothing occupied on entry
+    for k in ("world", "normal", "range", "flags", "d1"):
+        s[k] = np.concatenate([s[k], s[k]])
+    if len(s["world"]) <= 2800:
+        om, on = run_oracle_sim3(s, th, occupied=False)
+        gm, gn = orbhip.SearchByProjectionSim3(ex, s["world"], s["normal"], s["range"], s["flags"], s["d1"], s["u2"], s["d2"], None,
+                                               s["Scw"], s["cam4"], s["bounds"], th)
+        assert gn == on and np.array_equal(gm, om)

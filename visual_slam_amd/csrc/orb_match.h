@@ -229,15 +229,22 @@ struct ProjArgs {
 // of the keypoint's octave, levels [level - 1, level + 1] always, no mvuRight test, the acceptance
 // threshold is ORBdist, and a current keypoint that holds any map point is skipped: the ones that
 // hold one on entry (occupied2) and every one assigned here.
+// MODE 2, SIM3: ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th) of loop closing
+// (reference src/ORBmatcher.cc:287-400) on top of that variant: side 1 is a plain list of map points
+// (no keypoints), side 2 the key frame; the pose is Scw with its scale divided out (done by the host);
+// the depth must not be negative, the projection is formed as fx * (xc * invz) + cx with a float
+// reciprocal, KeyFrame::IsInImage excludes the upper bounds, the viewing direction must lie within 60
+// degrees of the point's normal, levels [level - 1, level], threshold TH_LOW, no rotation check.
 struct KeyframeArgs {
     const float2* dist_range1;    // per key-frame keypoint: mfMinDistance, mfMaxDistance of its map point
     const uint8_t* occupied2;     // per current keypoint: CurrentFrame.mvpMapPoints[i2] != NULL on entry (may be NULL)
+    const float* normal1;         // SIM3: GetNormal() of every map point
     int orb_dist;
     float log_scale_factor;
     int nlevels;
 };
 
-template <bool KEYFRAME>
+template <int MODE>
 __global__ __launch_bounds__(MP_THREADS) void k_search_proj(const GridKp* __restrict__ kp1, const float* __restrict__ world1,
                                                      const uint8_t* __restrict__ flags1, const uint8_t* __restrict__ desc1,
                                                      const int* __restrict__ cnt1, const GridKp* __restrict__ kp2,
@@ -245,6 +252,7 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_proj(const GridKp* __rest
                                                      const int* __restrict__ cnt2, int cap, const float* __restrict__ Tcw,
                                                      const int* __restrict__ level_mode, ProjArgs a, ScaleTab sf, KeyframeArgs kf,
                                                      int* __restrict__ match2, int* __restrict__ nmatches_out) {
+    constexpr bool KEYFRAME = MODE != 0, SIM3 = MODE == 2;
     extern __shared__ __align__(16) uint8_t mp_smem[];
     uint32_t* list1 = reinterpret_cast<uint32_t*>(mp_smem);                  // last: MP_LIST x (distance << 16 | current index), best first, occupancy ignored
     float2* pos2 = reinterpret_cast<float2*>(list1 + MP_LIST * (size_t)cap);  // current keypoints: position
@@ -303,11 +311,13 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_proj(const GridKp* __rest
             const float xc = (float)((double)(r00 * X + r01 * Y + r02 * Z) + (double)t0);
             const float yc = (float)((double)(r10 * X + r11 * Y + r12 * Z) + (double)t1);
             const float zc = (float)((double)(r20 * X + r21 * Y + r22 * Z) + (double)t2);
-            const float invzc = (float)(1.0 / (double)zc);
-            const float u = a.fx * xc * invzc + a.cx;
-            const float v = a.fy * yc * invzc + a.cy;
-            bool ok = (KEYFRAME || !(invzc < 0)) && u == u && v == v && !(u < a.min_x || u > a.max_x) && !(v < a.min_y || v > a.max_y);
-            int lvl = K1[i].octave & (ORB_MAX_LEVELS - 1);
+            const float invzc = SIM3 ? __fdiv_rn(1.0f, zc) : (float)(1.0 / (double)zc);
+            const float u = SIM3 ? a.fx * (xc * invzc) + a.cx : a.fx * xc * invzc + a.cx;
+            const float v = SIM3 ? a.fy * (yc * invzc) + a.cy : a.fy * yc * invzc + a.cy;
+            bool ok = SIM3 ? (!(zc < 0.0f) && u >= a.min_x && u < a.max_x && v >= a.min_y && v < a.max_y)   // src/ORBmatcher.cc:324-337
+                           : ((KEYFRAME || !(invzc < 0)) && u == u && v == v && !(u < a.min_x || u > a.max_x) && !(v < a.min_y || v > a.max_y));
+            int lvl = 0;
+            if (!KEYFRAME) lvl = K1[i].octave & (ORB_MAX_LEVELS - 1);
             if (KEYFRAME) {
                 // Ow = -Rcw^T tcw as the matrix expression computes it (accumulated in double, stored as float);
                 // PO = x3Dw - Ow in float, cv::norm in double (src/ORBmatcher.cc:1452,1480-1490)
@@ -318,6 +328,11 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_proj(const GridKp* __rest
                 const float dist3 = (float)sqrt((double)px * (double)px + (double)py * (double)py + (double)pz * (double)pz);
                 const float2 range = kf.dist_range1[o + i];
                 ok = ok && !(dist3 < 0.8f * range.x || dist3 > 1.2f * range.y);
+                if (SIM3) {                                    // PO.dot(Pn) < 0.5 * dist: both sides double (src/ORBmatcher.cc:349-352)
+                    const float* nr = kf.normal1 + 3 * (o + i);
+                    const double dot = (double)px * (double)nr[0] + (double)py * (double)nr[1] + (double)pz * (double)nr[2];
+                    ok = ok && !(dot < 0.5 * (double)dist3);
+                }
                 lvl = predict_scale(range.y, dist3, kf.log_scale_factor, kf.nlevels);
             }
             if (ok) {
@@ -353,7 +368,7 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_proj(const GridKp* __rest
         const int oct = st >> 2;
         const float r = a.th * sf.v[oct];
         const int lo = mode == 1 ? oct : mode == 2 ? 0 : oct - 1;           // octave range of GetFeaturesInArea's level test
-        const int hi = mode == 1 ? 255 : mode == 2 ? oct : oct + 1;
+        const int hi = mode == 1 ? 255 : (mode == 2 || SIM3) ? oct : oct + 1;
         const int min_cx = max(0, (int)floorf((p.x - a.min_x - r) * a.inv_w));
         const int max_cx = min(GRID_COLS - 1, (int)ceilf((p.x - a.min_x + r) * a.inv_w));
         const int min_cy = max(0, (int)floorf((p.y - a.min_y - r) * a.inv_h));

@@ -1191,7 +1191,7 @@ int orbhip_search_by_projection_batch_device(orbhip_extractor* e, int nframes, i
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     if (lds > 40 * 1024)
-        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_proj<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_proj<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProjArgs a;
     a.fx = prm->fx; a.fy = prm->fy; a.cx = prm->cx; a.cy = prm->cy; a.mbf = prm->mbf;
     a.min_x = prm->bounds[0]; a.max_x = prm->bounds[1]; a.min_y = prm->bounds[2]; a.max_y = prm->bounds[3];
@@ -1201,9 +1201,9 @@ int orbhip_search_by_projection_batch_device(orbhip_extractor* e, int nframes, i
     a.check_orientation = prm->check_orientation;
     ScaleTab sf;
     for (int l = 0; l < ORB_MAX_LEVELS; l++) sf.v[l] = e->sf[std::min(l, e->prm.nlevels - 1)];
-    hipLaunchKernelGGL(k_search_proj<false>, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const GridKp*>(d_kp_last), d_world_last,
+    hipLaunchKernelGGL(k_search_proj<0>, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const GridKp*>(d_kp_last), d_world_last,
                        d_flags_last, d_desc_last, d_cnt_last, reinterpret_cast<const GridKp*>(d_kp_cur), d_desc_cur, d_uright_cur,
-                       d_cnt_cur, cap, d_Tcw, d_level_mode, a, sf, KeyframeArgs{nullptr, nullptr, 0, 0.0f, 0}, d_match_cur, d_nmatches);
+                       d_cnt_cur, cap, d_Tcw, d_level_mode, a, sf, KeyframeArgs{nullptr, nullptr, nullptr, 0, 0.0f, 0}, d_match_cur, d_nmatches);
     HIP_TRY(e, hipGetLastError());
     return ORBHIP_OK;
 }
@@ -1278,7 +1278,7 @@ int orbhip_search_by_projection_keyframe_batch_device(orbhip_extractor* e, int n
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     if (lds > 40 * 1024)
-        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_proj<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_proj<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProjArgs a;
     a.fx = prm->fx; a.fy = prm->fy; a.cx = prm->cx; a.cy = prm->cy; a.mbf = prm->mbf;
     a.min_x = prm->bounds[0]; a.max_x = prm->bounds[1]; a.min_y = prm->bounds[2]; a.max_y = prm->bounds[3];
@@ -1288,12 +1288,113 @@ int orbhip_search_by_projection_keyframe_batch_device(orbhip_extractor* e, int n
     a.check_orientation = prm->check_orientation;
     ScaleTab sf;
     for (int l = 0; l < ORB_MAX_LEVELS; l++) sf.v[l] = e->sf[std::min(l, e->prm.nlevels - 1)];
-    const KeyframeArgs kf{reinterpret_cast<const float2*>(d_dist_range_kf), d_occupied_cur, orb_dist,
+    const KeyframeArgs kf{reinterpret_cast<const float2*>(d_dist_range_kf), d_occupied_cur, nullptr, orb_dist,
                           std::log((float)e->scale_factor_d), e->prm.nlevels};
-    hipLaunchKernelGGL(k_search_proj<true>, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const GridKp*>(d_kp_kf), d_world_kf,
+    hipLaunchKernelGGL(k_search_proj<1>, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const GridKp*>(d_kp_kf), d_world_kf,
                        d_flags_kf, d_desc_kf, d_cnt_kf, reinterpret_cast<const GridKp*>(d_kp_cur), d_desc_cur, (const float*)nullptr,
                        d_cnt_cur, cap, d_Tcw, (const int*)nullptr, a, sf, kf, d_match_cur, d_nmatches);
     HIP_TRY(e, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_decompose_sim3(const float* Scw, float* Tcw) {
+    if (!Scw || !Tcw) return ORBHIP_ERR_ARG;
+    // src/ORBmatcher.cc:296-299: scw = sqrt(sRcw.row(0).dot(sRcw.row(0))) (dot in double, scw a float), then
+    // sRcw / scw and t / scw as Mat / scalar: every element times the float value of 1.0 / scw
+    const double d = (double)Scw[0] * (double)Scw[0] + (double)Scw[1] * (double)Scw[1] + (double)Scw[2] * (double)Scw[2];
+    const float scw = (float)std::sqrt(d);
+    const float inv = (float)(1.0 / (double)scw);
+    for (int i = 0; i < 12; i++) Tcw[i] = Scw[i] * inv;
+    return ORBHIP_OK;
+}
+
+int orbhip_search_by_projection_sim3_batch_device(orbhip_extractor* e, int nframes, int cap, const float* d_world,
+                                                  const float* d_normal, const float* d_dist_range, const uint8_t* d_flags,
+                                                  const uint8_t* d_desc, const int* d_cnt_pts, const orbhip_keypoint* d_kp_kf,
+                                                  const uint8_t* d_desc_kf, const uint8_t* d_occupied_kf, const int* d_cnt_kf,
+                                                  const float* d_Tcw, const orbhip_projection_params* prm, int* d_match_kf,
+                                                  int* d_nmatches, void* stream) {
+    if (!e || nframes < 1 || cap < 1 || cap > 65534 || !d_world || !d_normal || !d_dist_range || !d_flags || !d_desc || !d_cnt_pts ||
+        !d_kp_kf || !d_desc_kf || !d_cnt_kf || !d_Tcw || !prm || !d_match_kf || !d_nmatches ||
+        !(prm->bounds[1] > prm->bounds[0]) || !(prm->bounds[3] > prm->bounds[2]))
+        return ORBHIP_ERR_ARG;
+    const size_t lds = (size_t)MP_LDS_PER_KP * cap + 16;
+    if (lds > 160 * 1024 - 20 * 1024) { e->err = "too many keypoints or map points per frame for the on-chip matcher state"; return ORBHIP_ERR_CAPACITY; }
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    if (lds > 40 * 1024)
+        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_proj<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProjArgs a;
+    a.fx = prm->fx; a.fy = prm->fy; a.cx = prm->cx; a.cy = prm->cy; a.mbf = prm->mbf;
+    a.min_x = prm->bounds[0]; a.max_x = prm->bounds[1]; a.min_y = prm->bounds[2]; a.max_y = prm->bounds[3];
+    a.inv_w = static_cast<float>(GRID_COLS) / (prm->bounds[1] - prm->bounds[0]);   // src/KeyFrame.cc: the frame's grid is copied
+    a.inv_h = static_cast<float>(GRID_ROWS) / (prm->bounds[3] - prm->bounds[2]);
+    a.th = prm->th;
+    a.check_orientation = 0;
+    ScaleTab sf;
+    for (int l = 0; l < ORB_MAX_LEVELS; l++) sf.v[l] = e->sf[std::min(l, e->prm.nlevels - 1)];
+    const KeyframeArgs kf{reinterpret_cast<const float2*>(d_dist_range), d_occupied_kf, d_normal, MT_TH_LOW,
+                          std::log((float)e->scale_factor_d), e->prm.nlevels};
+    hipLaunchKernelGGL(k_search_proj<2>, dim3(nframes), dim3(MP_THREADS), lds, s, (const GridKp*)nullptr, d_world, d_flags, d_desc,
+                       d_cnt_pts, reinterpret_cast<const GridKp*>(d_kp_kf), d_desc_kf, (const float*)nullptr, d_cnt_kf, cap, d_Tcw,
+                       (const int*)nullptr, a, sf, kf, d_match_kf, d_nmatches);
+    HIP_TRY(e, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_search_by_projection_sim3(orbhip_extractor* e, const float* world, const float* normal, const float* dist_range,
+                                     const uint8_t* flags, const uint8_t* desc, int n1, const orbhip_keypoint* kp_kf,
+                                     const uint8_t* desc_kf, const uint8_t* occupied_kf, int n2, const float* Scw,
+                                     const orbhip_projection_params* prm, int* match_kf, int* nmatches) {
+    if (!e || n1 < 0 || n2 < 0 || !Scw || !prm || !nmatches) return ORBHIP_ERR_ARG;
+    if (n2 > 0 && !match_kf) return ORBHIP_ERR_ARG;
+    for (int i = 0; i < n2; i++) match_kf[i] = -1;
+    if (n1 == 0 || n2 == 0) { *nmatches = 0; return ORBHIP_OK; }
+    if (!world || !normal || !dist_range || !flags || !desc || !kp_kf || !desc_kf) return ORBHIP_ERR_ARG;
+    float Tcw[12];
+    orbhip_decompose_sim3(Scw, Tcw);
+    HIP_TRY(e, hipSetDevice(e->device));
+    const int cap = std::max(n1, n2);
+    auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
+    const size_t kpb = up((size_t)cap * sizeof(orbhip_keypoint)), db = up((size_t)cap * 32), wb = up((size_t)cap * 12);
+    const size_t rb = up((size_t)cap * 8), fb = up((size_t)cap), mb = up((size_t)cap * 4);
+    const size_t need = 128 + kpb + 2 * db + 2 * wb + rb + 2 * fb + mb;
+    if (need > e->d_st_tmp_bytes) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        dfree(e->d_st_tmp);
+        HIP_TRY(e, hipMalloc(&e->d_st_tmp, need));
+        e->d_st_tmp_bytes = need;
+    }
+    uint8_t* p = e->d_st_tmp;
+    int* d_cnt = reinterpret_cast<int*>(p);                     // [0] n1, [1] n2, [2] matches
+    float* d_T = reinterpret_cast<float*>(p + 64); p += 128;
+    orbhip_keypoint* d_k2 = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
+    uint8_t* d_d1 = p; p += db;
+    uint8_t* d_d2 = p; p += db;
+    float* d_w = reinterpret_cast<float*>(p); p += wb;
+    float* d_n = reinterpret_cast<float*>(p); p += wb;
+    float* d_r = reinterpret_cast<float*>(p); p += rb;
+    uint8_t* d_f = p; p += fb;
+    uint8_t* d_o = p; p += fb;
+    int* d_m = reinterpret_cast<int*>(p);
+    const int cnt[3] = {n1, n2, 0};
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(d_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_T, Tcw, 12 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_d1, desc, (size_t)n1 * 32, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_w, world, (size_t)n1 * 12, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_n, normal, (size_t)n1 * 12, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_r, dist_range, (size_t)n1 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_f, flags, (size_t)n1, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_k2, kp_kf, (size_t)n2 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(d_d2, desc_kf, (size_t)n2 * 32, hipMemcpyHostToDevice));
+    if (occupied_kf) HIP_TRY(e, hipMemcpy(d_o, occupied_kf, (size_t)n2, hipMemcpyHostToDevice));
+    int rc = orbhip_search_by_projection_sim3_batch_device(e, 1, cap, d_w, d_n, d_r, d_f, d_d1, d_cnt, d_k2, d_d2,
+                                                           occupied_kf ? d_o : nullptr, d_cnt + 1, d_T, prm, d_m, d_cnt + 2, nullptr);
+    if (rc) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(match_kf, d_m, (size_t)n2 * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(nmatches, d_cnt + 2, sizeof(int), hipMemcpyDeviceToHost));
     return ORBHIP_OK;
 }
 

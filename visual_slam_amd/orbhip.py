@@ -41,6 +41,7 @@ EXPORTS = [
     "orbhip_search_by_projection_keyframe", "orbhip_search_by_projection_keyframe_batch_device",
     "orbhip_search_by_bow", "orbhip_search_by_bow_batch_device",
     "orbhip_search_by_bow_keyframes", "orbhip_search_by_bow_keyframes_batch_device",
+    "orbhip_decompose_sim3", "orbhip_search_by_projection_sim3", "orbhip_search_by_projection_sim3_batch_device",
 ]
 
 
@@ -114,6 +115,9 @@ def lib():
         L.orbhip_search_by_bow_batch_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 9 + [C.c_float, C.c_int, vp, vp, vp]
         L.orbhip_search_by_bow_keyframes.argtypes = [vp] * 5 + [C.c_int] + [vp] * 4 + [C.c_int, C.c_float, C.c_int, vp, ip]
         L.orbhip_search_by_bow_keyframes_batch_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 10 + [C.c_float, C.c_int, vp, vp, vp]
+        L.orbhip_decompose_sim3.argtypes = [vp, vp]
+        L.orbhip_search_by_projection_sim3.argtypes = [vp] * 6 + [C.c_int] + [vp] * 3 + [C.c_int, vp, vp, vp, ip]
+        L.orbhip_search_by_projection_sim3_batch_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 14 + [vp]
         L.orbhip_debug_logf.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
         L.orbhip_is_in_frustum.argtypes = [vp, vp, C.c_int, vp, vp, C.c_float, vp, ip]
         L.orbhip_is_in_frustum_batch_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_float, vp, vp, vp]
@@ -266,6 +270,25 @@ def search_by_bow_batch_device(ex, nframes, cap, d_kp_kf, d_desc_kf, d_node_kf, 
     ex._check(lib().orbhip_search_by_bow_batch_device(ex._h, nframes, cap, d_kp_kf, d_desc_kf, d_node_kf, d_flags_kf, d_cnt_kf, d_kp_f,
                                                       d_desc_f, d_node_f, d_cnt_f, float(nnratio), int(bool(check_orientation)),
                                                       d_match_f, d_nmatches, stream))
+
+
+def SearchByProjectionSim3(ex, world, normal, dist_range, flags, desc, kp_kf, desc_kf, occupied_kf, Scw, cam4, bounds, th):
+    """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (reference src/ORBmatcher.cc:287-400, loop
+    closing) on the device. Scw: 12 floats, sR row-major then t. Returns (match_kf, nmatches)."""
+    kp_kf = np.ascontiguousarray(kp_kf, KP_DTYPE)
+    w = np.ascontiguousarray(world, np.float32).reshape(-1, 3); nr = np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
+    rg = np.ascontiguousarray(dist_range, np.float32).reshape(-1, 2)
+    fl = np.ascontiguousarray(flags, np.uint8)
+    d1 = np.ascontiguousarray(desc, np.uint8); d2 = np.ascontiguousarray(desc_kf, np.uint8)
+    oc = None if occupied_kf is None else np.ascontiguousarray(occupied_kf, np.uint8)
+    S = np.ascontiguousarray(Scw, np.float32).reshape(12)
+    prm = projection_params(cam4, 0.0, bounds, float(int(th)), False)
+    m = np.full(max(len(kp_kf), 1), -1, np.int32)
+    n = C.c_int(0)
+    ex._check(lib().orbhip_search_by_projection_sim3(ex._h, _ptr(w), _ptr(nr), _ptr(rg), _ptr(fl), _ptr(d1), len(w), _ptr(kp_kf), _ptr(d2),
+                                                     None if oc is None else _ptr(oc), len(kp_kf), _ptr(S), C.byref(prm), _ptr(m),
+                                                     C.byref(n)))
+    return m[:len(kp_kf)], n.value
 
 
 def search_by_projection_batch_device(ex, nframes, cap, d_kp_last, d_world_last, d_flags_last, d_desc_last, d_cnt_last,
