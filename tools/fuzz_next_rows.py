@@ -108,6 +108,17 @@ def main():
         gm4, gn4 = orbhip.SearchByProjectionKeyFrame(ex, u1, world, drange, flags & 1, d1, u2, d2, occ_kf, Tcw, cam[:4], bounds, th, odist, ori)
         if gn4 != on4 or not np.array_equal(gm4, om4):
             bad += 1; print(tag, "KEYFRAME PROJECTION MISMATCH", gn4, on4, int((gm4 != om4).sum()))
+        # the loop-closing variant: a similarity with a random scale, normals around the viewing direction
+        Ow_ = -(R.T @ Tcw[9:12].astype(np.float64))
+        view = world.astype(np.float64) - Ow_
+        nrm = view / np.maximum(np.linalg.norm(view, axis=1, keepdims=True), 1e-9) + rng.normal(0, 0.5, view.shape)
+        nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+        Scw = (Tcw.astype(np.float64) * float(rng.uniform(0.3, 3.0))).astype(np.float32)
+        th_i = int(rng.choice([3, 4, 10]))
+        om6, on6 = O.search_by_projection_sim3(world, nrm, drange, flags & 1, d1, u2, d2, occ_kf, Scw, cam[:4], bounds, sf, prm[1], th_i)
+        gm6, gn6 = orbhip.SearchByProjectionSim3(ex, world, nrm, drange, flags & 1, d1, u2, d2, occ_kf, Scw, cam[:4], bounds, th_i)
+        if gn6 != on6 or not np.array_equal(gm6, om6):
+            bad += 1; print(tag, "SIM3 PROJECTION MISMATCH", gn6, on6, int((gm6 != om6).sum()))
         # the bag-of-words matcher with synthetic node ids (a hash of descriptor bits; now and then a feature without a node)
         nn = int(rng.choice([1, 7, 100, 1000]))
         def nodes(d):
