@@ -7,6 +7,7 @@ same function on the same pairs (one thread).
 Usage: python tools/match_bench.py [--pairs 256] [--width 1241 --height 376] [--steps 5]
 """
 import argparse
+import ctypes as C
 import json
 import pathlib
 import sys
@@ -225,6 +226,86 @@ def main():
     except ImportError:
         pass
     print(json.dumps(out))
+
+    # ---- the remaining entry points, device time only (their parity is covered by tests/): 256 frames or pairs per launch
+    L = orbhip.lib()
+
+    def timed(fn):
+        fn(); stream.synchronize()
+        with torch.cuda.stream(stream):
+            e0.record(stream)
+            for _ in range(args.steps):
+                fn()
+            e1.record(stream)
+        stream.synchronize()
+        return e0.elapsed_time(e1) / args.steps
+
+    # Frame::isInFrustum on the local map of the section above
+    mpw = np.zeros((n, cap_mp), orbhip.MAPPOINT_DTYPE)
+    for i in range(n):
+        m = int(cnt_mp[i])
+        zz = np.full(m, Z, np.float32)
+        mpw["pos"][i, :m] = np.stack([(mp["proj_x"][i, :m] - cx) * Z / fx, (mp["proj_y"][i, :m] - cy) * Z / fy, zz], axis=1)
+        mpw["normal"][i, :m] = (0, 0, 1)
+        mpw["min_distance"][i, :m] = 1.0; mpw["max_distance"][i, :m] = 40.0
+        mpw["flags"][i, :m] = 3
+    pose = np.tile(np.concatenate([np.eye(3).ravel(), [0, 0, 0], [0, 0, 0]]).astype(np.float32), (n, 1))
+    with torch.cuda.stream(stream):
+        d_mpw = torch.from_numpy(mpw.view(np.uint8).reshape(n, cap_mp, 36)).to(dev); d_pose = torch.from_numpy(pose).to(dev)
+        d_track = torch.zeros((n, cap_mp, 24), dtype=torch.uint8, device=dev); d_nvis = torch.zeros((n,), dtype=torch.int32, device=dev)
+    stream.synchronize()
+    pp = orbhip.projection_params(KITTI[:4], 0.5 * fx, bounds, 0.0, False)
+    ms = timed(lambda: orbhip.is_in_frustum_batch_device(ex, n, cap_mp, d_mpw.data_ptr(), d_cmp.data_ptr(), d_pose.data_ptr(), pp, 0.5,
+                                                         d_track.data_ptr(), d_nvis.data_ptr(), stream=sp))
+    print(json.dumps({"op": "Frame::isInFrustum", "frames": n, "map_points_per_frame": float(cnt_mp.mean()), "ms_per_batch": round(ms, 3),
+                      "frames_per_s": round(n / ms * 1e3, 1), "mean_in_view": float(d_nvis.cpu().numpy().mean())}))
+
+    # SearchForInitialization on the (last, current) pairs
+    prev = hu1[..., :2].astype(np.float32).copy()
+    with torch.cuda.stream(stream):
+        d_prev0 = torch.from_numpy(prev).to(dev); d_prev = d_prev0.clone()
+        m12 = torch.zeros((n, cap), dtype=torch.int32, device=dev)
+    stream.synchronize()
+    b_f = np.ascontiguousarray(bounds, np.float32)
+
+    def step_init():
+        d_prev.copy_(d_prev0)
+        ex._check(L.orbhip_search_for_initialization_batch_device(ex._h, n, u1.data_ptr(), d1.data_ptr(), c1.data_ptr(), u2.data_ptr(),
+                                                                  d2.data_ptr(), c2.data_ptr(), cap, orbhip._ptr(b_f), d_prev.data_ptr(), 100,
+                                                                  0.9, 1, m12.data_ptr(), nm.data_ptr(), sp))
+    with torch.cuda.stream(stream):
+        ms = timed(step_init)
+    print(json.dumps({"op": "SearchForInitialization(F1, F2)", "pairs": n, "window": 100, "ms_per_batch": round(ms, 3),
+                      "pairs_per_s": round(n / ms * 1e3, 1), "mean_matches": float(nm.cpu().numpy().mean())}))
+
+    # the relocalisation and loop-closing variants of the projection matcher on the (last, current) pairs
+    maxd = (Z * np.array(ex.GetScaleFactors(), np.float32)[hk1.view(orbhip.KP_DTYPE)["octave"].reshape(n, cap)]).astype(np.float32)
+    drange = np.stack([maxd / 3.5832, maxd], axis=2).astype(np.float32)
+    nrm = np.zeros((n, cap, 3), np.float32); nrm[..., 2] = 1.0
+    with torch.cuda.stream(stream):
+        d_rng = torch.from_numpy(drange).to(dev); d_nrm = torch.from_numpy(nrm).to(dev)
+    stream.synchronize()
+    prm_kf = orbhip.projection_params(KITTI[:4], 0.0, bounds, 10.0, True)
+    ms = timed(lambda: ex._check(L.orbhip_search_by_projection_keyframe_batch_device(
+        ex._h, n, cap, u1.data_ptr(), dw.data_ptr(), d_rng.data_ptr(), df.data_ptr(), d1.data_ptr(), c1.data_ptr(), u2.data_ptr(),
+        d2.data_ptr(), None, c2.data_ptr(), dT.data_ptr(), C.byref(prm_kf), 100, match.data_ptr(), nm.data_ptr(), sp)))
+    print(json.dumps({"op": "SearchByProjection(CurrentFrame, pKF, sAlreadyFound)", "pairs": n, "th": 10, "ms_per_batch": round(ms, 3),
+                      "pairs_per_s": round(n / ms * 1e3, 1), "mean_matches": float(nm.cpu().numpy().mean())}))
+    ms = timed(lambda: ex._check(L.orbhip_search_by_projection_sim3_batch_device(
+        ex._h, n, cap, dw.data_ptr(), d_nrm.data_ptr(), d_rng.data_ptr(), df.data_ptr(), d1.data_ptr(), c1.data_ptr(), u2.data_ptr(),
+        d2.data_ptr(), None, c2.data_ptr(), dT.data_ptr(), C.byref(prm_kf), match.data_ptr(), nm.data_ptr(), sp)))
+    print(json.dumps({"op": "SearchByProjection(pKF, Scw, vpPoints, vpMatched)", "pairs": n, "th": 10, "ms_per_batch": round(ms, 3),
+                      "pairs_per_s": round(n / ms * 1e3, 1), "mean_matches": float(nm.cpu().numpy().mean())}))
+
+    # SearchByBoW between two key frames
+    with torch.cuda.stream(stream):
+        d_f2 = torch.ones((n, cap), dtype=torch.uint8, device=dev)
+    stream.synchronize()
+    ms = timed(lambda: ex._check(L.orbhip_search_by_bow_keyframes_batch_device(
+        ex._h, n, cap, k1.data_ptr(), d1.data_ptr(), d_nk.data_ptr(), d_fl.data_ptr(), c1.data_ptr(), k2.data_ptr(), d2.data_ptr(),
+        d_nf.data_ptr(), d_f2.data_ptr(), c2.data_ptr(), 0.75, 1, match.data_ptr(), nm.data_ptr(), sp)))
+    print(json.dumps({"op": "SearchByBoW(pKF1, pKF2)", "pairs": n, "nodes": 100, "ms_per_batch": round(ms, 3),
+                      "pairs_per_s": round(n / ms * 1e3, 1), "mean_matches": float(nm.cpu().numpy().mean())}))
 
 
 if __name__ == "__main__":
