@@ -372,7 +372,7 @@ int orbhip_search_by_bow_keyframes(orbhip_extractor* e, const orbhip_keypoint* k
  * Output: d_match[f][idx] = index of the map point the reference assigns to F.mvpMapPoints[idx]
  * (the last one, if several), -1 where it assigns none; d_nmatches[f] = the returned count.
  * Asynchronous on `stream` (NULL: the handle's). One workgroup per frame; 17 bytes of on-chip state
- * per map point slot and 18 per keypoint slot must fit 140 KB, else ORBHIP_ERR_CAPACITY. */
+ * per map point slot and 17 per keypoint slot must fit 140 KB, else ORBHIP_ERR_CAPACITY. */
 typedef struct orbhip_track_point {
     float proj_x, proj_y, proj_xr, view_cos;
     int32_t level, flags;

@@ -20,15 +20,27 @@
 #define MT_TH_LOW 50          // ORBmatcher::TH_LOW (src/ORBmatcher.cc:39)
 #define MT_HISTO 30           // ORBmatcher::HISTO_LENGTH (src/ORBmatcher.cc:40)
 
+// Minimum of a 64-bit key over the 64 lanes, the same value in every lane. DPP row shifts and row
+// broadcasts (as in wave_scan_incl; lanes without a source keep the identity ~0), no LDS traffic.
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {
-        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, s, 64);
-        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), s, 64);
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-        v = o < v ? o : v;
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+#define WMIN_STEP(CTRL, ROWS)                                                                                   \
+    {                                                                                                           \
+        const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)lo, CTRL, ROWS, 0xf, false);        \
+        const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)hi, CTRL, ROWS, 0xf, false);        \
+        const bool less = ohi < hi || (ohi == hi && olo < lo);                                                  \
+        lo = less ? olo : lo;                                                                                   \
+        hi = less ? ohi : hi;                                                                                   \
     }
-    return v;
+    WMIN_STEP(0x111, 0xf)   // row_shr:1
+    WMIN_STEP(0x112, 0xf)   // row_shr:2
+    WMIN_STEP(0x114, 0xf)   // row_shr:4
+    WMIN_STEP(0x118, 0xf)   // row_shr:8: lane 15 of every row holds the row's minimum
+    WMIN_STEP(0x142, 0xa)   // row_bcast:15 into rows 1, 3
+    WMIN_STEP(0x143, 0xc)   // row_bcast:31 into rows 2, 3: lane 63 holds the minimum
+#undef WMIN_STEP
+    const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)lo, 63), rhi = (unsigned)__builtin_amdgcn_readlane((int)hi, 63);
+    return ((unsigned long long)rhi << 32) | rlo;
 }
 
 // Grid (frames), one wave per workgroup. Dynamic LDS per F2 keypoint: position (8 bytes), grid cell
@@ -751,7 +763,7 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_init_par(const GridKp* __
 struct TrackPt { float x, y, xr, view_cos; int level, flags; };   // flags: 1 = mbTrackInView and not bad, 2 = Observations() > 0
 
 #define ML_LDS_PER_MP 17      // dynamic LDS bytes per map point slot
-#define ML_LDS_PER_KP 18      // and per keypoint slot
+#define ML_LDS_PER_KP 17      // and per keypoint slot
 
 __global__ __launch_bounds__(MP_THREADS) void k_search_map(const TrackPt* __restrict__ mp, const uint8_t* __restrict__ desc1,
                                                            const int* __restrict__ cnt1, int cap1,
@@ -766,9 +778,8 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_map(const TrackPt* __rest
     float* ur2 = reinterpret_cast<float*>(pos2 + cap2);                      // mvuRight
     uint16_t* sorted2 = reinterpret_cast<uint16_t*>(ur2 + cap2);             // keypoint indices bucketed by grid cell
     uint16_t* cell2 = sorted2 + cap2;                                        // grid cell, 0xFFFF = outside
-    uint8_t* oct2 = reinterpret_cast<uint8_t*>(cell2 + cap2);                // octave
-    uint8_t* occ2 = oct2 + cap2;                                             // holds a point with observations
-    uint8_t* st1 = occ2 + cap2;                                              // map point: 1 usable | 2 observed
+    uint8_t* oo2 = reinterpret_cast<uint8_t*>(cell2 + cap2);                 // octave | 0x80 when it holds a point with observations
+    uint8_t* st1 = oo2 + cap2;                                               // map point: 1 usable | 2 observed
     __shared__ uint32_t s_cur[GRID_CELLS];
     __shared__ uint16_t s_start[GRID_CELLS + 2];
     __shared__ uint32_t s_magic[GRID_ROWS + 1];
@@ -790,8 +801,7 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_map(const TrackPt* __rest
         pos2[i] = make_float2(k.x, k.y);
         ur2[i] = uright2 ? uright2[o2 + i] : -1.0f;
         cell2[i] = (uint16_t)(cell < 0 ? 0xFFFF : cell);
-        oct2[i] = (uint8_t)k.octave;
-        occ2[i] = occupied2 ? (uint8_t)(occupied2[o2 + i] != 0) : (uint8_t)0;
+        oo2[i] = (uint8_t)((k.octave & 0x7F) | ((occupied2 && occupied2[o2 + i] != 0) ? 0x80 : 0));
         m2[i] = -1;
         if (cell >= 0) atomicAdd(&s_cur[cell], 1u);
     }
@@ -837,11 +847,12 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_map(const TrackPt* __rest
             const int ke = s_start[cell + 1];
             for (int k = s_start[cell]; k < ke; k++) {
                 const int i2 = sorted2[k];
-                const int oc = oct2[i2];
+                const int oo = oo2[i2];
+                if (oo & 0x80) continue;                       // src/ORBmatcher.cc:88-90
+                const int oc = oo;
                 if (oc < lo || oc > hi) continue;
                 const float2 q = pos2[i2];
                 if (!(fabsf(q.x - t.x) < r && fabsf(q.y - t.y) < r)) continue;
-                if (occ2[i2]) continue;                        // src/ORBmatcher.cc:88-90
                 const float u2 = ur2[i2];
                 if (u2 > 0 && fabsf(t.xr - u2) > r) continue;  // src/ORBmatcher.cc:92-97
                 const uint4* d2p = reinterpret_cast<const uint4*>(desc2 + (o2 + i2) * 32);
@@ -880,24 +891,41 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_map(const TrackPt* __rest
     }
     __syncthreads();
 
-    // ---- phase B: the reference's loop order, one wave, scalar control flow on LDS state
+    // ---- phase B: the reference's loop order, one wave, scalar control flow on LDS state. The states and
+    // lists of 64 map points at a time are fetched into registers (one per lane) and handed out with
+    // v_readlane, so that only the occupancy look-ups remain as dependent LDS reads.
     int made = 0;
     if (wv == 0) {
-        for (int i = 0; i < n1; i++) {
-            const int st = __builtin_amdgcn_readfirstlane((int)st1[i]);
+        for (int i0 = 0; i0 < n1; i0 += 64) {
+          const int il = min(i0 + lane, n1 - 1);
+          const int stv = st1[il];
+          const uint4 lv = *reinterpret_cast<const uint4*>(&list1[MP_LIST * il]);
+          const int nblk = min(64, n1 - i0);
+          for (int k = 0; k < nblk; k++) {
+            const int i = i0 + k;
+            const int st = __builtin_amdgcn_readlane(stv, k);
             if (!(st & 1)) continue;
+            const uint32_t le[MP_LIST] = {(uint32_t)__builtin_amdgcn_readlane((int)lv.x, k), (uint32_t)__builtin_amdgcn_readlane((int)lv.y, k),
+                                          (uint32_t)__builtin_amdgcn_readlane((int)lv.z, k), (uint32_t)__builtin_amdgcn_readlane((int)lv.w, k)};
+            // octave and occupancy of the (up to four) listed keypoints in one LDS round trip: lane q reads entry q's
+            const uint32_t myc = lane == 0 ? le[0] : lane == 1 ? le[1] : lane == 2 ? le[2] : le[3];
+            const int myo = (lane < MP_LIST && myc < MP_END) ? (int)oo2[myc & 0xFFFF] : 0;
+            const int lo_[MP_LIST] = {__builtin_amdgcn_readlane(myo, 0), __builtin_amdgcn_readlane(myo, 1),
+                                      __builtin_amdgcn_readlane(myo, 2), __builtin_amdgcn_readlane(myo, 3)};
             uint32_t best = MP_NONE, second = MP_NONE;         // distance << 16 | keypoint
+            int best_lv = 0, second_lv = 0;
             bool decided = false;
             uint32_t term = MP_NONE, last_real = MP_NONE;      // how the list ended (MP_NONE also stands for "all slots used")
+#pragma unroll
             for (int q = 0; q < MP_LIST; q++) {
-                const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)list1[MP_LIST * i + q]);
+                const uint32_t c = le[q];
                 if (c >= MP_END) { term = c; break; }
                 last_real = c;
-                if (__builtin_amdgcn_readfirstlane((int)occ2[c & 0xFFFF])) continue;
+                if (lo_[q] & 0x80) continue;
                 if (best == MP_NONE) {
-                    best = c;
+                    best = c; best_lv = lo_[q];
                     if ((c >> 16) > MP_TH_HIGH) { decided = true; break; }   // nothing closer is free: no match
-                } else { second = c; decided = true; break; }
+                } else { second = c; second_lv = lo_[q]; decided = true; break; }
             }
             if (!decided) {
                 if (term == MP_END) decided = true;            // the list was complete: what was found is all there is
@@ -913,20 +941,21 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_map(const TrackPt* __rest
                 const unsigned long long k2 = wave_min_u64(b1);
                 best = k1 == ~0ull ? MP_NONE : (uint32_t)((k1 >> 40) << 16) | (uint32_t)(k1 & 0xFFFF);
                 second = k2 == ~0ull ? MP_NONE : (uint32_t)((k2 >> 40) << 16) | (uint32_t)(k2 & 0xFFFF);
+                best_lv = best == MP_NONE ? 0 : __builtin_amdgcn_readfirstlane((int)oo2[best & 0xFFFF]);
+                second_lv = second == MP_NONE ? 0 : __builtin_amdgcn_readfirstlane((int)oo2[second & 0xFFFF]);
             }
             if (best == MP_NONE) continue;
             const int bestDist = (int)(best >> 16), bestIdx = (int)(best & 0xFFFF);
             if (bestDist > MP_TH_HIGH) continue;               // src/ORBmatcher.cc:116
             if (second != MP_NONE) {
-                const int lv1 = __builtin_amdgcn_readfirstlane((int)oct2[bestIdx]);
-                const int lv2 = __builtin_amdgcn_readfirstlane((int)oct2[second & 0xFFFF]);
-                if (lv1 == lv2 && (float)bestDist > nnratio * (float)(int)(second >> 16)) continue;   // src/ORBmatcher.cc:118-119
+                if ((best_lv & 0x7F) == (second_lv & 0x7F) && (float)bestDist > nnratio * (float)(int)(second >> 16)) continue;   // src/ORBmatcher.cc:118-119
             }
             made++;
             if (lane == 0) {
                 m2[bestIdx] = i;                               // a point without observations is simply overwritten
-                occ2[bestIdx] = (uint8_t)((st >> 1) & 1);
+                if (st & 2) oo2[bestIdx] = (uint8_t)(best_lv | 0x80);
             }
+          }
         }
         if (lane == 0) nmatches_out[f] = made;
     }
