@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Random-parameter sweep of the device paths next to the extraction (rectification, the
-matchers) against the oracle. One-off robustness tool: prints the failing draws, exit status 1 if any.
+"""Random-parameter sweep of the device paths next to the extraction (rectification, stereo matching,
+undistortion and grid, the matchers) against the oracle. One-off robustness tool: prints the failing draws, exit status 1 if any.
 
 Usage: python tools/fuzz_next_rows.py [--cases 60] [--seed 1]
 """
@@ -60,6 +60,30 @@ def main():
         if not ok:
             bad += 1; print(tag, "RECTIFICATION MISMATCH")
         ex.set_rectification(None, None)
+        # stereo matching of (img, img moved by a random disparity) and undistortion + grid of the left keypoints
+        try:
+            exR = orbhip.ORBextractor(*prm); oR = O.OracleExtractor(*prm)
+            disp = int(rng.integers(1, 40))
+            right = shifted(img, -disp, int(rng.integers(-1, 2)))
+            kl, dl = ex(img); kr, dr = exR(right)
+            okl, odl = o.extract(img); okr, odr = oR.extract(right)
+            fxs = float(rng.uniform(300, 900)); bfs = fxs * float(rng.uniform(0.05, 0.6))
+            gu, gd, gn = orbhip.ComputeStereoMatches(ex, exR, kl, dl, kr, dr, bfs / fxs, bfs)
+            ou, od, on_ = O.stereo_match(o, oR, okl, odl, okr, odr, bfs / fxs, bfs)
+            if gn != on_ or not np.array_equal(gu.view(np.uint32), ou.view(np.uint32)) or not np.array_equal(gd.view(np.uint32), od.view(np.uint32)):
+                bad += 1; print(tag, "STEREO MISMATCH", gn, on_)
+            camd = (fxs, fxs * float(rng.uniform(0.9, 1.1)), w / 2.0, h / 2.0, float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.2, 0.2)),
+                    float(rng.uniform(-0.002, 0.002)), float(rng.uniform(-0.002, 0.002)), float(rng.uniform(-0.1, 0.1)))
+            bd = O.image_bounds(camd, w, h)
+            if bd[1] > bd[0] and bd[3] > bd[2] and len(okl):
+                gb = orbhip.ComputeImageBounds(camd, w, h)
+                gun, ggs, ggi = orbhip.UndistortAndAssignToGrid(ex, kl, camd, gb)
+                oun, ogs, ogi = O.undistort_grid(camd, bd, okl)
+                if not np.array_equal(gb.view(np.uint32), bd.view(np.uint32)) or not np.array_equal(gun.view(np.uint8), oun.view(np.uint8)) or \
+                        not np.array_equal(ggs, ogs) or not np.array_equal(ggi, ogi):
+                    bad += 1; print(tag, "UNDISTORT / GRID MISMATCH")
+        except (RuntimeError, orbhip.OrbHipError) as e:
+            print(tag, "stereo refused:", e)
         # matchers on (img, shifted img)
         dx, dy = int(rng.integers(-20, 21)), int(rng.integers(-12, 13))
         cam = (float(rng.uniform(300, 900)), float(rng.uniform(300, 900)), w / 2.0 + float(rng.uniform(-20, 20)), h / 2.0, 0.0, 0, 0, 0, 0)
