@@ -441,15 +441,30 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_proj(const GridKp* __rest
     __syncthreads();
     if (wv == 0) {
         // the reference's loop order; LDS operations of the one wave complete in issue order
+        // States and lists of 64 keypoints at a time are fetched into registers (one per lane) and handed out
+        // with v_readlane; the occupancy of a keypoint's listed candidates is read by lanes 0..3 in one round trip.
         int made = 0;
-        for (int i = 0; i < n1; i++) {
-            const int st = __builtin_amdgcn_readfirstlane((int)st1[i]);       // the same in every lane: scalar control flow
+        for (int i0 = 0; i0 < n1; i0 += 64) {
+          const int il = min(i0 + lane, n1 - 1);
+          const int stv = st1[il];
+          const uint4 lv = *reinterpret_cast<const uint4*>(&list1[MP_LIST * il]);
+          const int nblk = min(64, n1 - i0);
+          for (int k = 0; k < nblk; k++) {
+            const int i = i0 + k;
+            const int st = __builtin_amdgcn_readlane(stv, k);                 // the same in every lane: scalar control flow
             if (!(st & 1)) continue;
+            const uint32_t le[MP_LIST] = {(uint32_t)__builtin_amdgcn_readlane((int)lv.x, k), (uint32_t)__builtin_amdgcn_readlane((int)lv.y, k),
+                                          (uint32_t)__builtin_amdgcn_readlane((int)lv.z, k), (uint32_t)__builtin_amdgcn_readlane((int)lv.w, k)};
+            const uint32_t myc = lane == 0 ? le[0] : lane == 1 ? le[1] : lane == 2 ? le[2] : le[3];
+            const int myo = (lane < MP_LIST && myc < MP_END) ? (int)occ2[myc & 0xFFFF] : 0;
+            const int oc[MP_LIST] = {__builtin_amdgcn_readlane(myo, 0), __builtin_amdgcn_readlane(myo, 1),
+                                     __builtin_amdgcn_readlane(myo, 2), __builtin_amdgcn_readlane(myo, 3)};
             uint32_t b = MP_NONE;                              // MP_NONE after the walk: the list did not decide
+#pragma unroll
             for (int r = 0; r < MP_LIST; r++) {
-                const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)list1[MP_LIST * i + r]);
+                const uint32_t c = le[r];
                 if (c >= MP_END) { b = c; break; }
-                if (!__builtin_amdgcn_readfirstlane((int)occ2[c & 0xFFFF])) { b = c; break; }   // still free: the reference's choice
+                if (!oc[r]) { b = c; break; }                  // still free: the reference's choice
             }
             if (b == MP_NONE) {                                // every listed candidate was taken meanwhile: search again
                 uint32_t e[MP_LIST];
@@ -465,6 +480,7 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_proj(const GridKp* __rest
                 taken1[i] = (uint16_t)i2;
                 bin1[i] = 0xFE;                                // matched; its rotation bin is filled in below, in parallel
             }
+          }
         }
         if (lane == 0) s_made = made;
     }
