@@ -210,6 +210,18 @@ int orbhip_undistort_grid_batch_device(orbhip_extractor* e, int nframes, const o
 int orbhip_undistort_grid(orbhip_extractor* e, const orbhip_keypoint* kp, int n, const orbhip_camera* cam,
                           const float bounds[4], orbhip_keypoint* kp_un, int* grid_start, int* grid_idx);
 
+/* Frame::ComputeStereoFromRGBD (src/Frame.cc:655-672) for frames in device memory, with the depth scaling
+ * of Tracking::GrabImageRGBD in front of it (imDepth.convertTo(imDepth, CV_32F, mDepthMapFactor) when the
+ * factor differs from 1 or the map is not CV_32F): d_depth holds nframes depth maps (unsigned 16-bit
+ * when depth_is_u16, else float; strides in bytes), d_kp the raw keypoints (mvKeys: the depth is read at
+ * their truncated position), d_kp_un the undistorted ones (mvKeysUn). d_uright / d_depth_out
+ * [nframes][cap] receive mvuRight and mvDepth (-1 where the depth is not positive). A keypoint outside
+ * the map gets -1 (the reference would read out of bounds). Asynchronous on `stream`. */
+int orbhip_stereo_from_rgbd_batch_device(orbhip_extractor* e, int nframes, const orbhip_keypoint* d_kp, const orbhip_keypoint* d_kp_un,
+                                         const int* d_counts, int cap, const void* d_depth, int depth_is_u16, int width, int height,
+                                         size_t row_stride, size_t frame_stride, float depth_map_factor, float mbf,
+                                         float* d_uright, float* d_depth_out, void* stream);
+
 /* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)
  * (src/ORBmatcher.cc:402-517; called with ORBmatcher(0.9, true) and windowSize 100 at
  * src/Tracking.cc:588-589) for `nframes` frame pairs in device memory. d_kp_un1 / d_kp_un2 are the

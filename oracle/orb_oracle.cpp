@@ -976,6 +976,30 @@ void orbo_undistort_grid(const float* cam, const float* bounds, const orbo_keypo
     grid_start[COLS * ROWS] = pos;
 }
 
+/* Frame::ComputeStereoFromRGBD (src/Frame.cc:655-672) behind the conversion of Tracking::GrabImageRGBD
+ * (imDepth.convertTo(imDepth, CV_32F, mDepthMapFactor) when |factor - 1| > 1e-5 or the map is not CV_32F;
+ * cvtScale to float multiplies in float). depth: height rows of `row_stride` bytes, unsigned 16-bit when
+ * depth_u16, else float. kp = mvKeys, kp_un = mvKeysUn. */
+void orbo_stereo_from_rgbd(const orbo_keypoint* kp, const orbo_keypoint* kp_un, int n, const void* depth, int depth_u16, int width,
+                           int height, size_t row_stride, float mDepthMapFactor, float mbf, float* mvuRight, float* mvDepth) {
+    const bool convert = (std::fabs(mDepthMapFactor - 1.0f) > 1e-5) || depth_u16;
+    for (int i = 0; i < n; i++) {
+        mvuRight[i] = -1; mvDepth[i] = -1;
+        const float v = kp[i].y, u = kp[i].x;
+        const int row = (int)v, col = (int)u;                  /* Mat::at<float>(int, int) called with floats */
+        if (row < 0 || row >= height || col < 0 || col >= width) continue;   /* out of bounds in the reference */
+        const uint8_t* r = static_cast<const uint8_t*>(depth) + (size_t)row * row_stride;
+        float d;
+        if (depth_u16) { uint16_t t; std::memcpy(&t, r + 2 * (size_t)col, 2); d = (float)t; }
+        else std::memcpy(&d, r + 4 * (size_t)col, 4);
+        if (convert) d = d * mDepthMapFactor;
+        if (d > 0) {
+            mvDepth[i] = d;
+            mvuRight[i] = kp_un[i].x - mbf / d;
+        }
+    }
+}
+
 /* ORBmatcher::SearchForInitialization (reference src/ORBmatcher.cc:402-517) with
  * Frame::GetFeaturesInArea (src/Frame.cc:351-401), Frame::AssignFeaturesToGrid / PosInGrid for F2's
  * grid (src/Frame.cc:255-270, 403-411), ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1611-1627)

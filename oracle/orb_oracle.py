@@ -93,6 +93,8 @@ def lib():
         L.orbo_search_by_bow_keyframes.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.orbo_search_by_projection_sim3.argtypes = [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4 + \
             [C.c_float, C.c_int, C.c_int, C.c_void_p]
+        L.orbo_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_float,
+                                            C.c_float, C.c_void_p, C.c_void_p]
         L.orbo_libm_logf.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orbo_libm_sincos.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orbo_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
@@ -460,3 +462,15 @@ def search_by_projection_sim3(world, normal, dist_range, flags, desc, kp_kf, des
                                              _ptr(np.ascontiguousarray(cam4, np.float32)), _ptr(np.ascontiguousarray(bounds, np.float32)),
                                              _ptr(sf), float(np.float32(scale_factor)), len(sf), int(th), _ptr(m))
     return m[:len(kp_kf)], n
+
+
+def stereo_from_rgbd(kp, kp_un, depth, depth_map_factor, mbf):
+    """Frame::ComputeStereoFromRGBD behind GrabImageRGBD's conversion: depth is an (H, W) uint16 or float32 map.
+    Returns (mvuRight, mvDepth)."""
+    kp = np.ascontiguousarray(kp, KP_DTYPE); kp_un = np.ascontiguousarray(kp_un, KP_DTYPE)
+    depth = np.ascontiguousarray(depth)
+    assert depth.dtype in (np.uint16, np.float32)
+    ur = np.zeros(max(len(kp), 1), np.float32); dp = np.zeros(max(len(kp), 1), np.float32)
+    lib().orbo_stereo_from_rgbd(_ptr(kp), _ptr(kp_un), len(kp), _ptr(depth), int(depth.dtype == np.uint16), depth.shape[1], depth.shape[0],
+                                depth.strides[0], float(np.float32(depth_map_factor)), float(np.float32(mbf)), _ptr(ur), _ptr(dp))
+    return ur[:len(kp)], dp[:len(kp)]

@@ -93,3 +93,33 @@ __global__ __launch_bounds__(256) void k_undistort_grid(const GridKp* __restrict
         }
     }
 }
+
+
+// Frame::ComputeStereoFromRGBD (reference src/Frame.cc:655-672) with the depth scaling that precedes
+// it in Tracking::GrabImageRGBD (src/Tracking.cc: imDepth.convertTo(imDepth, CV_32F, mDepthMapFactor)
+// when the factor differs from 1 by more than 1e-5 or the map is not CV_32F): the depth at the
+// truncated position of the raw keypoint, mvuRight = undistorted x - mbf / depth where the depth is
+// positive. depth_u16: the map holds unsigned 16-bit values, else floats; convert: apply the factor
+// (a float multiplication, as cvtScale does for these types).
+__global__ __launch_bounds__(256) void k_stereo_from_rgbd(const GridKp* __restrict__ kp, const GridKp* __restrict__ kp_un,
+                                                          const int* __restrict__ counts, int cap, const uint8_t* __restrict__ depth,
+                                                          size_t row_stride, size_t frame_stride, int width, int height,
+                                                          int depth_u16, int convert, float factor, float mbf,
+                                                          float* __restrict__ uright, float* __restrict__ out_depth) {
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cap) return;
+    const size_t o = (size_t)f * cap + i;
+    float ur = -1.0f, dp = -1.0f;
+    if (i < min(counts[f], cap)) {
+        const int u = (int)kp[o].x, v = (int)kp[o].y;          // Mat::at<float>(float, float): the indices are truncated
+        if (u >= 0 && u < width && v >= 0 && v < height) {      // (outside the map the reference reads out of bounds)
+            const uint8_t* row = depth + (size_t)f * frame_stride + (size_t)v * row_stride;
+            float d = depth_u16 ? (float)reinterpret_cast<const uint16_t*>(row)[u] : reinterpret_cast<const float*>(row)[u];
+            if (convert) d = d * factor;
+            if (d > 0) { dp = d; ur = kp_un[o].x - __fdiv_rn(mbf, d); }
+        }
+    }
+    uright[o] = ur;
+    out_depth[o] = dp;
+}

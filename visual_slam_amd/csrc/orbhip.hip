@@ -996,6 +996,24 @@ int orbhip_image_bounds(const orbhip_camera* cam, int width, int height, float b
     return ORBHIP_OK;
 }
 
+int orbhip_stereo_from_rgbd_batch_device(orbhip_extractor* e, int nframes, const orbhip_keypoint* d_kp, const orbhip_keypoint* d_kp_un,
+                                         const int* d_counts, int cap, const void* d_depth, int depth_is_u16, int width, int height,
+                                         size_t row_stride, size_t frame_stride, float depth_map_factor, float mbf,
+                                         float* d_uright, float* d_depth_out, void* stream) {
+    if (!e || nframes < 1 || cap < 1 || !d_kp || !d_kp_un || !d_counts || !d_depth || width < 1 || height < 1 || !d_uright || !d_depth_out ||
+        row_stride < (size_t)width * (depth_is_u16 ? 2 : 4))
+        return ORBHIP_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    // src/Tracking.cc (GrabImageRGBD): the map is converted when the factor is not 1 or the type is not CV_32F
+    const int convert = (std::fabs(depth_map_factor - 1.0f) > 1e-5) || depth_is_u16;
+    hipLaunchKernelGGL(k_stereo_from_rgbd, dim3((cap + 255) / 256, nframes), dim3(256), 0, s, reinterpret_cast<const GridKp*>(d_kp),
+                       reinterpret_cast<const GridKp*>(d_kp_un), d_counts, cap, static_cast<const uint8_t*>(d_depth), row_stride,
+                       frame_stride, width, height, depth_is_u16 ? 1 : 0, convert, depth_map_factor, mbf, d_uright, d_depth_out);
+    HIP_TRY(e, hipGetLastError());
+    return ORBHIP_OK;
+}
+
 int orbhip_undistort_grid_batch_device(orbhip_extractor* e, int nframes, const orbhip_keypoint* d_kp,
                                        const int* d_counts, int cap, const orbhip_camera* cam,
                                        const float bounds[4], orbhip_keypoint* d_kp_un, int* d_grid_start,

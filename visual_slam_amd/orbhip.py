@@ -41,7 +41,7 @@ EXPORTS = [
     "orbhip_search_by_projection_keyframe", "orbhip_search_by_projection_keyframe_batch_device",
     "orbhip_search_by_bow", "orbhip_search_by_bow_batch_device",
     "orbhip_search_by_bow_keyframes", "orbhip_search_by_bow_keyframes_batch_device",
-    "orbhip_decompose_sim3", "orbhip_search_by_projection_sim3", "orbhip_search_by_projection_sim3_batch_device",
+    "orbhip_stereo_from_rgbd_batch_device", "orbhip_decompose_sim3", "orbhip_search_by_projection_sim3", "orbhip_search_by_projection_sim3_batch_device",
 ]
 
 
@@ -118,6 +118,8 @@ def lib():
         L.orbhip_decompose_sim3.argtypes = [vp, vp]
         L.orbhip_search_by_projection_sim3.argtypes = [vp] * 6 + [C.c_int] + [vp] * 3 + [C.c_int, vp, vp, vp, ip]
         L.orbhip_search_by_projection_sim3_batch_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 14 + [vp]
+        L.orbhip_stereo_from_rgbd_batch_device.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_size_t,
+                                                           C.c_size_t, C.c_float, C.c_float, vp, vp, vp]
         L.orbhip_debug_logf.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
         L.orbhip_is_in_frustum.argtypes = [vp, vp, C.c_int, vp, vp, C.c_float, vp, ip]
         L.orbhip_is_in_frustum_batch_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_float, vp, vp, vp]
@@ -351,6 +353,14 @@ def search_map_points_batch_device(ex, nframes, cap_mp, d_mp, d_desc_mp, d_cnt_m
     ex._check(lib().orbhip_search_map_points_batch_device(ex._h, nframes, cap_mp, d_mp, d_desc_mp, d_cnt_mp, cap_kp, d_kp, d_desc,
                                                           d_uright, d_occupied, d_cnt_kp, _ptr(b), float(th), float(nnratio),
                                                           d_match, d_nmatches, stream))
+
+
+def stereo_from_rgbd_batch_device(ex, nframes, d_kp, d_kp_un, d_counts, cap, d_depth, depth_is_u16, width, height, row_stride,
+                                  frame_stride, depth_map_factor, mbf, d_uright, d_depth_out, stream=None):
+    """Frame::ComputeStereoFromRGBD (reference src/Frame.cc:655-672) on device-resident frames and depth maps."""
+    ex._check(lib().orbhip_stereo_from_rgbd_batch_device(ex._h, nframes, d_kp, d_kp_un, d_counts, cap, d_depth, int(bool(depth_is_u16)),
+                                                         width, height, row_stride, frame_stride, float(depth_map_factor), float(mbf),
+                                                         d_uright, d_depth_out, stream))
 
 
 def ComputeStereoMatches(left, right, kp_l, desc_l, kp_r, desc_r, mb, mbf):
