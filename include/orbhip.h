@@ -222,6 +222,16 @@ int orbhip_stereo_from_rgbd_batch_device(orbhip_extractor* e, int nframes, const
                                          size_t row_stride, size_t frame_stride, float depth_map_factor, float mbf,
                                          float* d_uright, float* d_depth_out, void* stream);
 
+/* Frame::UnprojectStereo (src/Frame.cc:674-687) for every keypoint of nframes frames in device memory:
+ * d_kp_un = mvKeysUn, d_depth = mvDepth ([nframes][cap], as the stereo / RGB-D calls above write it),
+ * d_pose_wc = per frame mRwc row-major (9 floats) and mOw (3). d_world[nframes][cap][3] receives the world
+ * positions, d_valid[nframes][cap] 1 where the depth is positive (the reference returns an empty Mat
+ * otherwise; the position is zeroed there). flags for orbhip_search_by_projection_batch_device can be
+ * built from d_valid. Asynchronous on `stream`. */
+int orbhip_unproject_stereo_batch_device(orbhip_extractor* e, int nframes, const orbhip_keypoint* d_kp_un, const float* d_depth,
+                                         const int* d_counts, int cap, const float* d_pose_wc, float fx, float fy, float cx, float cy,
+                                         float* d_world, uint8_t* d_valid, void* stream);
+
 /* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)
  * (src/ORBmatcher.cc:402-517; called with ORBmatcher(0.9, true) and windowSize 100 at
  * src/Tracking.cc:588-589) for `nframes` frame pairs in device memory. d_kp_un1 / d_kp_un2 are the

@@ -976,6 +976,31 @@ void orbo_undistort_grid(const float* cam, const float* bounds, const orbo_keypo
     grid_start[COLS * ROWS] = pos;
 }
 
+/* Frame::UnprojectStereo (src/Frame.cc:674-687) for n keypoints: kp_un = mvKeysUn, depth = mvDepth, pose_wc = mRwc
+ * row-major (9) then mOw (3), cam = {fx, fy, cx, cy} (invfx = 1.0f / fx as the constructors compute it).
+ * world[3 i ..] receives mRwc * x3Dc + mOw (the small-matrix product for CV_32F), valid[i] = 1, where
+ * the depth is positive; zeros and 0 where the reference returns an empty Mat. */
+void orbo_unproject_stereo(const orbo_keypoint* kp_un, const float* depth, int n, const float* pose_wc, const float* cam,
+                           float* world, uint8_t* valid) {
+    const float cx = cam[2], cy = cam[3];
+    const float invfx = 1.0f / cam[0], invfy = 1.0f / cam[1];
+    for (int i = 0; i < n; i++) {
+        world[3 * i] = world[3 * i + 1] = world[3 * i + 2] = 0.0f; valid[i] = 0;
+        const float z = depth[i];
+        if (z > 0) {
+            const float u = kp_un[i].x, v = kp_un[i].y;
+            const float x = (u - cx) * z * invfx;
+            const float y = (v - cy) * z * invfy;
+            const float c[3] = {x, y, z};
+            for (int r = 0; r < 3; r++) {
+                const float t = pose_wc[3 * r] * c[0] + pose_wc[3 * r + 1] * c[1] + pose_wc[3 * r + 2] * c[2];
+                world[3 * i + r] = (float)((double)t * 1.0 + (double)pose_wc[9 + r] * 1.0);
+            }
+            valid[i] = 1;
+        }
+    }
+}
+
 /* Frame::ComputeStereoFromRGBD (src/Frame.cc:655-672) behind the conversion of Tracking::GrabImageRGBD
  * (imDepth.convertTo(imDepth, CV_32F, mDepthMapFactor) when |factor - 1| > 1e-5 or the map is not CV_32F;
  * cvtScale to float multiplies in float). depth: height rows of `row_stride` bytes, unsigned 16-bit when

@@ -125,6 +125,9 @@ int orbo_search_by_projection_keyframe(const orbo_keypoint* k_kf, const float* w
                                        const uint8_t* desc_cur, const uint8_t* occupied_cur, int n2, const float* Tcw,
                                        const float* cam, const float* bounds, const float* scale_factors, float scale_factor,
                                        int nlevels, float th, int ORBdist, int mbCheckOrientation, int* match_cur);
+/* Frame::UnprojectStereo (src/Frame.cc:674-687) for arrays of keypoints. */
+void orbo_unproject_stereo(const orbo_keypoint* kp_un, const float* depth, int n, const float* pose_wc, const float* cam,
+                           float* world, uint8_t* valid);
 /* Frame::ComputeStereoFromRGBD (src/Frame.cc:655-672) with the depth conversion of Tracking::GrabImageRGBD. */
 void orbo_stereo_from_rgbd(const orbo_keypoint* kp, const orbo_keypoint* kp_un, int n, const void* depth, int depth_u16, int width,
                            int height, size_t row_stride, float mDepthMapFactor, float mbf, float* mvuRight, float* mvDepth);

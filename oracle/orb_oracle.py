@@ -95,6 +95,7 @@ def lib():
             [C.c_float, C.c_int, C.c_int, C.c_void_p]
         L.orbo_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_float,
                                             C.c_float, C.c_void_p, C.c_void_p]
+        L.orbo_unproject_stereo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orbo_libm_logf.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orbo_libm_sincos.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orbo_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
@@ -474,3 +475,13 @@ def stereo_from_rgbd(kp, kp_un, depth, depth_map_factor, mbf):
     lib().orbo_stereo_from_rgbd(_ptr(kp), _ptr(kp_un), len(kp), _ptr(depth), int(depth.dtype == np.uint16), depth.shape[1], depth.shape[0],
                                 depth.strides[0], float(np.float32(depth_map_factor)), float(np.float32(mbf)), _ptr(ur), _ptr(dp))
     return ur[:len(kp)], dp[:len(kp)]
+
+
+def unproject_stereo(kp_un, depth, pose_wc, cam4):
+    """Frame::UnprojectStereo for every keypoint: returns (world [n, 3], valid [n])."""
+    kp_un = np.ascontiguousarray(kp_un, KP_DTYPE); depth = np.ascontiguousarray(depth, np.float32)
+    n = len(kp_un)
+    world = np.zeros((max(n, 1), 3), np.float32); valid = np.zeros(max(n, 1), np.uint8)
+    lib().orbo_unproject_stereo(_ptr(kp_un), _ptr(depth), n, _ptr(np.ascontiguousarray(pose_wc, np.float32).reshape(12)),
+                                _ptr(np.ascontiguousarray(cam4, np.float32)), _ptr(world), _ptr(valid))
+    return world[:n], valid[:n]

@@ -123,3 +123,35 @@ __global__ __launch_bounds__(256) void k_stereo_from_rgbd(const GridKp* __restri
     uright[o] = ur;
     out_depth[o] = dp;
 }
+
+
+// Frame::UnprojectStereo (reference src/Frame.cc:674-687) for every keypoint of a frame: the world position
+// mRwc * ((u - cx) * z * invfx, (v - cy) * z * invfy, z) + mOw of a keypoint with a positive depth
+// (OpenCV's small-matrix product: float products summed in float, mOw added in double). pose: per frame
+// mRwc row-major (9) and mOw (3). valid[i] = 1 where a point was produced (the reference returns an
+// empty Mat otherwise); world[i] is (0, 0, 0) there.
+__global__ __launch_bounds__(256) void k_unproject_stereo(const GridKp* __restrict__ kp_un, const float* __restrict__ depth,
+                                                          const int* __restrict__ counts, int cap, const float* __restrict__ pose,
+                                                          float cx, float cy, float invfx, float invfy,
+                                                          float* __restrict__ world, uint8_t* __restrict__ valid) {
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cap) return;
+    const size_t o = (size_t)f * cap + i;
+    const float* T = pose + 12 * (size_t)f;
+    float wx = 0.0f, wy = 0.0f, wz = 0.0f;
+    uint8_t ok = 0;
+    if (i < min(counts[f], cap)) {
+        const float z = depth[o];
+        if (z > 0) {
+            const float x = (kp_un[o].x - cx) * z * invfx;
+            const float y = (kp_un[o].y - cy) * z * invfy;
+            wx = (float)((double)(T[0] * x + T[1] * y + T[2] * z) + (double)T[9]);
+            wy = (float)((double)(T[3] * x + T[4] * y + T[5] * z) + (double)T[10]);
+            wz = (float)((double)(T[6] * x + T[7] * y + T[8] * z) + (double)T[11]);
+            ok = 1;
+        }
+    }
+    world[3 * o] = wx; world[3 * o + 1] = wy; world[3 * o + 2] = wz;
+    valid[o] = ok;
+}

@@ -1014,6 +1014,21 @@ int orbhip_stereo_from_rgbd_batch_device(orbhip_extractor* e, int nframes, const
     return ORBHIP_OK;
 }
 
+int orbhip_unproject_stereo_batch_device(orbhip_extractor* e, int nframes, const orbhip_keypoint* d_kp_un, const float* d_depth,
+                                         const int* d_counts, int cap, const float* d_pose_wc, float fx, float fy, float cx, float cy,
+                                         float* d_world, uint8_t* d_valid, void* stream) {
+    if (!e || nframes < 1 || cap < 1 || !d_kp_un || !d_depth || !d_counts || !d_pose_wc || !d_world || !d_valid || !(fx != 0.0f) ||
+        !(fy != 0.0f))
+        return ORBHIP_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    const float invfx = 1.0f / fx, invfy = 1.0f / fy;          // src/Frame.cc: invfx = 1.0f/fx in the constructors
+    hipLaunchKernelGGL(k_unproject_stereo, dim3((cap + 255) / 256, nframes), dim3(256), 0, s, reinterpret_cast<const GridKp*>(d_kp_un),
+                       d_depth, d_counts, cap, d_pose_wc, cx, cy, invfx, invfy, d_world, d_valid);
+    HIP_TRY(e, hipGetLastError());
+    return ORBHIP_OK;
+}
+
 int orbhip_undistort_grid_batch_device(orbhip_extractor* e, int nframes, const orbhip_keypoint* d_kp,
                                        const int* d_counts, int cap, const orbhip_camera* cam,
                                        const float bounds[4], orbhip_keypoint* d_kp_un, int* d_grid_start,

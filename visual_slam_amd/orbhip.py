@@ -41,7 +41,7 @@ EXPORTS = [
     "orbhip_search_by_projection_keyframe", "orbhip_search_by_projection_keyframe_batch_device",
     "orbhip_search_by_bow", "orbhip_search_by_bow_batch_device",
     "orbhip_search_by_bow_keyframes", "orbhip_search_by_bow_keyframes_batch_device",
-    "orbhip_stereo_from_rgbd_batch_device", "orbhip_decompose_sim3", "orbhip_search_by_projection_sim3", "orbhip_search_by_projection_sim3_batch_device",
+    "orbhip_stereo_from_rgbd_batch_device", "orbhip_unproject_stereo_batch_device", "orbhip_decompose_sim3", "orbhip_search_by_projection_sim3", "orbhip_search_by_projection_sim3_batch_device",
 ]
 
 
@@ -120,6 +120,8 @@ def lib():
         L.orbhip_search_by_projection_sim3_batch_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 14 + [vp]
         L.orbhip_stereo_from_rgbd_batch_device.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_size_t,
                                                            C.c_size_t, C.c_float, C.c_float, vp, vp, vp]
+        L.orbhip_unproject_stereo_batch_device.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_float, C.c_float, C.c_float, C.c_float,
+                                                           vp, vp, vp]
         L.orbhip_debug_logf.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
         L.orbhip_is_in_frustum.argtypes = [vp, vp, C.c_int, vp, vp, C.c_float, vp, ip]
         L.orbhip_is_in_frustum_batch_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_float, vp, vp, vp]
@@ -361,6 +363,12 @@ def stereo_from_rgbd_batch_device(ex, nframes, d_kp, d_kp_un, d_counts, cap, d_d
     ex._check(lib().orbhip_stereo_from_rgbd_batch_device(ex._h, nframes, d_kp, d_kp_un, d_counts, cap, d_depth, int(bool(depth_is_u16)),
                                                          width, height, row_stride, frame_stride, float(depth_map_factor), float(mbf),
                                                          d_uright, d_depth_out, stream))
+
+
+def unproject_stereo_batch_device(ex, nframes, d_kp_un, d_depth, d_counts, cap, d_pose_wc, cam4, d_world, d_valid, stream=None):
+    """Frame::UnprojectStereo (reference src/Frame.cc:674-687) for all keypoints of device-resident frames."""
+    ex._check(lib().orbhip_unproject_stereo_batch_device(ex._h, nframes, d_kp_un, d_depth, d_counts, cap, d_pose_wc, float(cam4[0]),
+                                                         float(cam4[1]), float(cam4[2]), float(cam4[3]), d_world, d_valid, stream))
 
 
 def ComputeStereoMatches(left, right, kp_l, desc_l, kp_r, desc_r, mb, mbf):
