@@ -1,6 +1,7 @@
 """The device entry points chained as a stereo tracking front-end would chain them, on one stream
 and without a host round trip in between: rectification + extraction of both eyes at two time steps,
-stereo matching (reference src/Frame.cc:481-653), undistortion (src/Frame.cc:422-449), the
+stereo matching (reference src/Frame.cc:481-653), undistortion (src/Frame.cc:422-449), unprojection
+(src/Frame.cc:674-687), the
 motion-model matcher (src/ORBmatcher.cc:1324-1445) between the two steps and the local-map matcher
 (src/ORBmatcher.cc:46-127) on the second. Every stage is compared
 with the oracle run stage by stage on the host: besides the arithmetic this checks the ordering of
@@ -74,15 +75,22 @@ def test_stereo_front_end_chain_matches_oracle_stage_by_stage():
         gL._check(lib.orbhip_undistort_grid_batch_device(gL._h, n, kl.data_ptr(), cl.data_ptr(), cap, orbhip._ptr(cam_c), orbhip._ptr(b_c),
                                                          un["L" + t].data_ptr(), gs.data_ptr(), gi.data_ptr(), sp))
     stream.synchronize()
-    # map points of step 0: left keypoints with a stereo depth, back-projected (the host's job in the reference)
-    hu0, hdp0, hc0 = un["L0"].cpu().numpy(), dp["0"].cpu().numpy(), res["L0"][2].cpu().numpy()
-    z = np.where(hdp0 > 0, hdp0, 1.0)
-    world = np.stack([(hu0[..., 0] - cx) * z / fx, (hu0[..., 1] - cy) * z / fy, z], axis=2).astype(np.float32)
-    flags = (hdp0 > 0).astype(np.uint8) * 3
+    # map points of step 0: left keypoints with a stereo depth, back-projected on the device (Frame::UnprojectStereo,
+    # the last frame's camera = the world frame); usable and observed where a depth exists
+    ident = np.tile(np.concatenate([np.eye(3).ravel(), [0, 0, 0]]).astype(np.float32), (n, 1))
     Tcw = np.stack([np.concatenate([np.eye(3).ravel(), [dx * Z / fx, dy * Z / fy, 0.0]]) for dx, dy in motion]).astype(np.float32)
     with torch.cuda.stream(stream):
-        dw, df, dT = (torch.from_numpy(a).to(dev) for a in (world, flags, Tcw))
+        d_ident, dT = torch.from_numpy(ident).to(dev), torch.from_numpy(Tcw).to(dev)
+        dw = torch.zeros((n, cap, 3), dtype=torch.float32, device=dev)
+        dvalid = torch.zeros((n, cap), dtype=torch.uint8, device=dev)
     stream.synchronize()
+    orbhip.unproject_stereo_batch_device(gL, n, un["L0"].data_ptr(), dp["0"].data_ptr(), res["L0"][2].data_ptr(), cap, d_ident.data_ptr(),
+                                         KITTI[:4], dw.data_ptr(), dvalid.data_ptr(), stream=sp)
+    with torch.cuda.stream(stream):
+        df = dvalid * 3
+    stream.synchronize()
+    hu0, hc0 = un["L0"].cpu().numpy(), res["L0"][2].cpu().numpy()
+    world, flags = dw.cpu().numpy(), df.cpu().numpy()
     prm_p = orbhip.projection_params(KITTI[:4], bf, bounds, 7.0, True)
     orbhip.search_by_projection_batch_device(gL, n, cap, un["L0"].data_ptr(), dw.data_ptr(), df.data_ptr(), res["L0"][1].data_ptr(),
                                              res["L0"][2].data_ptr(), un["L1"].data_ptr(), res["L1"][1].data_ptr(), ur["1"].data_ptr(),
@@ -145,6 +153,8 @@ def test_stereo_front_end_chain_matches_oracle_stage_by_stage():
         u0 = O.undistort_grid(KITTI, bounds, o["L0"][1])[0]
         u1 = O.undistort_grid(KITTI, bounds, o["L1"][1])[0]
         c0, c1 = len(u0), len(u1)
+        ow, ov = O.unproject_stereo(u0, st["0"][1], ident[i], KITTI[:4])
+        assert np.array_equal(world[i, :c0].view(np.uint32), ow.view(np.uint32)) and np.array_equal(flags[i, :c0], ov * 3), i
         om, on = O.search_by_projection(u0, world[i, :c0], flags[i, :c0], o["L0"][2], u1, o["L1"][2], st["1"][0], Tcw[i],
                                         KITTI[:4], bf, bounds, o["L0"][0].table(0), 7.0, 0, True)
         assert int(nmatch[i].item()) == on, i
