@@ -45,6 +45,10 @@ __device__ __forceinline__ void level0_edge_group(const uint8_t* __restrict__ sr
 
 // Grid x: the blocks of 64 interior groups, then one more block that does the nb border groups of
 // the block's 4 * L0_RPT rows (their latency-bound byte path runs beside the streaming copy).
+// ALIGNED: every 16-byte source group is 16-byte aligned (base and strides are multiples of 16). Otherwise a
+// group starts at any byte: it is read as five dwords from the 4-byte aligned address below it (four
+// when it happens to be aligned) and shifted into place; the shift is the same for a whole row.
+template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_level0_interior(const uint8_t* __restrict__ src, size_t row_stride,
                                                          size_t frame_stride, uint8_t* __restrict__ pyr,
                                                          LevelGeom g, int g_lo, int g_hi, int nb) {
@@ -70,7 +74,17 @@ __global__ __launch_bounds__(256) void k_level0_interior(const uint8_t* __restri
     for (int k = 0; k < L0_RPT; k++) {                                  // all loads first: a wave is short
         int sy = min(r0 + k, g.rows - 1) - ORB_OY;
         sy = sy < 0 ? -sy : (sy >= g.h ? 2 * (g.h - 1) - sy : sy);     // the border is narrower than the image
-        v[k] = __builtin_nontemporal_load(reinterpret_cast<const nv4*>(S + (size_t)sy * row_stride));   // read once
+        const uint8_t* p = S + (size_t)sy * row_stride;
+        if (ALIGNED) {
+            v[k] = __builtin_nontemporal_load(reinterpret_cast<const nv4*>(p));   // read once
+        } else {
+            const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(p) & 3);   // wave-uniform: lanes differ by multiples of 16
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(p - sh);
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
+            const uint32_t d4 = sh ? q[4] : 0u;                 // never past the row's last byte when the group is aligned
+            v[k] = nv4{__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                       __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
+        }
     }
 #pragma unroll
     for (int k = 0; k < L0_RPT; k++)

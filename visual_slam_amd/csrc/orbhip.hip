@@ -380,10 +380,15 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
                 hipLaunchKernelGGL(k_level0_color<3>, grid, dim3(256), 0, s, d_imgs, row_stride, frame_stride, W.d_pyr, g, n16, rgb, aligned16);
             else
                 hipLaunchKernelGGL(k_level0_color<4>, grid, dim3(256), 0, s, d_imgs, row_stride, frame_stride, W.d_pyr, g, n16, rgb, aligned16);
-        } else if (aligned16 && i_hi > i_lo && g.h > ORB_EDGE && g.w > ORB_OX) {
+        } else if (i_hi > i_lo && g.h > ORB_EDGE && g.w > ORB_OX) {
             // the border groups of a row (the first i_lo and those from i_hi on) ride in an extra block per row band
-            hipLaunchKernelGGL(k_level0_interior, dim3((i_hi - i_lo + 63) / 64 + 1, (g.rows + 4 * L0_RPT - 1) / (4 * L0_RPT), frames), blk2, 0, s,
-                               d_imgs, row_stride, frame_stride, W.d_pyr, g, i_lo, i_hi, n16 - (i_hi - i_lo));
+            const dim3 grid((i_hi - i_lo + 63) / 64 + 1, (g.rows + 4 * L0_RPT - 1) / (4 * L0_RPT), frames);
+            if (aligned16)
+                hipLaunchKernelGGL(k_level0_interior<true>, grid, blk2, 0, s, d_imgs, row_stride, frame_stride, W.d_pyr, g, i_lo, i_hi,
+                                   n16 - (i_hi - i_lo));
+            else
+                hipLaunchKernelGGL(k_level0_interior<false>, grid, blk2, 0, s, d_imgs, row_stride, frame_stride, W.d_pyr, g, i_lo, i_hi,
+                                   n16 - (i_hi - i_lo));
         } else {
             hipLaunchKernelGGL(k_level0_edges, dim3((g.rows * n16 + 255) / 256, frames), dim3(256), 0, s,
                                d_imgs, row_stride, frame_stride, W.d_pyr, g, n16, n16, n16);
