@@ -448,11 +448,13 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_proj(const GridKp* __rest
           const int il = min(i0 + lane, n1 - 1);
           const int stv = st1[il];
           const uint4 lv = *reinterpret_cast<const uint4*>(&list1[MP_LIST * il]);
-          const int nblk = min(64, n1 - i0);
-          for (int k = 0; k < nblk; k++) {
+          // keypoints without a usable point or with an empty, complete list decide nothing: only the others are visited
+          unsigned long long todo = __ballot(i0 + lane < n1 && (stv & 1) && lv.x != MP_END);
+          while (todo) {
+            const int k = __builtin_ctzll(todo);
+            todo &= todo - 1;
             const int i = i0 + k;
             const int st = __builtin_amdgcn_readlane(stv, k);                 // the same in every lane: scalar control flow
-            if (!(st & 1)) continue;
             const uint32_t le[MP_LIST] = {(uint32_t)__builtin_amdgcn_readlane((int)lv.x, k), (uint32_t)__builtin_amdgcn_readlane((int)lv.y, k),
                                           (uint32_t)__builtin_amdgcn_readlane((int)lv.z, k), (uint32_t)__builtin_amdgcn_readlane((int)lv.w, k)};
             const uint32_t myc = lane == 0 ? le[0] : lane == 1 ? le[1] : lane == 2 ? le[2] : le[3];
@@ -916,11 +918,13 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_map(const TrackPt* __rest
           const int il = min(i0 + lane, n1 - 1);
           const int stv = st1[il];
           const uint4 lv = *reinterpret_cast<const uint4*>(&list1[MP_LIST * il]);
-          const int nblk = min(64, n1 - i0);
-          for (int k = 0; k < nblk; k++) {
+          // points that are not usable or whose list is empty and complete decide nothing: only the others are visited
+          unsigned long long todo = __ballot(i0 + lane < n1 && (stv & 1) && lv.x != MP_END);
+          while (todo) {
+            const int k = __builtin_ctzll(todo);
+            todo &= todo - 1;
             const int i = i0 + k;
             const int st = __builtin_amdgcn_readlane(stv, k);
-            if (!(st & 1)) continue;
             const uint32_t le[MP_LIST] = {(uint32_t)__builtin_amdgcn_readlane((int)lv.x, k), (uint32_t)__builtin_amdgcn_readlane((int)lv.y, k),
                                           (uint32_t)__builtin_amdgcn_readlane((int)lv.z, k), (uint32_t)__builtin_amdgcn_readlane((int)lv.w, k)};
             // octave and occupancy of the (up to four) listed keypoints in one LDS round trip: lane q reads entry q's
