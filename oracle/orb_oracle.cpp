@@ -1143,8 +1143,8 @@ int orbo_search_for_initialization(const orbo_keypoint* k1, const uint8_t* d1, i
 }
 
 /* bForward / bBackward of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono)
- * (src/ORBmatcher.cc:1330-1337): twc = -Rcw^T tcw, tlc = Rlw twc + tlw (cv::Mat products of CV_32F
- * matrices: accumulated in double, stored as float); forward when tlc.z > mb, backward when
+ * (src/ORBmatcher.cc:1330-1337): twc = -Rcw^T tcw (a cv::Mat product with a transposed operand:
+ * accumulated in double, stored as float), tlc = Rlw twc + tlw (small-matrix path); forward when tlc.z > mb, backward when
  * -tlc.z > mb, neither for a monocular frame. T* = {R row-major (9), t (3)} of mTcw.
  * Returns 0 (neither), 1 (forward) or 2 (backward; the reference tests forward first). */
 int orbo_projection_level_mode(const float* Tcw_cur, const float* Tcw_last, float mb, int bMono) {
@@ -1154,9 +1154,10 @@ int orbo_projection_level_mode(const float* Tcw_cur, const float* Tcw_last, floa
         for (int k = 0; k < 3; k++) s += (double)Tcw_cur[3 * k + r] * (double)Tcw_cur[9 + k];
         twc[r] = (float)(-s);
     }
-    double s = 0;
-    for (int k = 0; k < 3; k++) s += (double)Tcw_last[6 + k] * (double)twc[k];
-    const float tlc_z = (float)(s + (double)Tcw_last[11]);
+    /* no transposed operand here: the small-matrix path (float products summed in float, the
+     * addend added in double), as for Rcw * x3Dw + tcw */
+    const float rz = Tcw_last[6] * twc[0] + Tcw_last[7] * twc[1] + Tcw_last[8] * twc[2];
+    const float tlc_z = (float)((double)rz + (double)Tcw_last[11]);
     if (bMono) return 0;
     if (tlc_z > mb) return 1;
     if (-tlc_z > mb) return 2;

@@ -106,3 +106,31 @@ def test_stereo_batch_device_matches_oracle():
         assert n == len(okl) and int(nm[i].item()) == on
         assert np.array_equal(ur[i, :n].cpu().numpy().view(np.uint32), ou.view(np.uint32))
         assert np.array_equal(dp[i, :n].cpu().numpy().view(np.uint32), od.view(np.uint32))
+
+
+def test_one_pair_of_instances_across_input_sizes():
+    """The same two instances extract a small pair, match it and build the feature grid, then extract a
+    larger pair (the pinned input staging grows) and do all of it again: the matcher's scratch buffers
+    must survive the growth of the input staging."""
+    from oracle import orb_oracle as O
+    from visual_slam_amd import orbhip
+    cam = (718.856, 718.856, 607.1928, 185.2157, 0.0, 0.0, 0.0, 0.0, 0.0)
+    prm = (1000, 1.2, 8, 20, 7)
+    gL, gR = orbhip.ORBextractor(*prm), orbhip.ORBextractor(*prm)
+    for kind, w, h, idx in (("blocks", 320, 240, 3), ("blocks", 752, 480, 4), ("noise", 320, 240, 5)):
+        left, right = make_pair(kind, w, h, idx)
+        oL, oR = O.OracleExtractor(*prm), O.OracleExtractor(*prm)
+        okl, odl = oL.extract(left)
+        okr, odr = oR.extract(right)
+        ou, od, on = O.stereo_match(oL, oR, okl, odl, okr, odr, BF / FX, BF)
+        gkl, gdl = gL(left, fetch_pyramid=False)
+        gkr, gdr = gR(right, fetch_pyramid=False)
+        gu, gd, gn = orbhip.ComputeStereoMatches(gL, gR, gkl, gdl, gkr, gdr, BF / FX, BF)
+        assert gn == on
+        assert np.array_equal(ou.view(np.uint32), gu.view(np.uint32))
+        assert np.array_equal(od.view(np.uint32), gd.view(np.uint32))
+        ob = O.image_bounds(cam, w, h)
+        oun, ogs, ogi = O.undistort_grid(cam, ob, okl)
+        gun, ggs, ggi = orbhip.UndistortAndAssignToGrid(gL, gkl, cam, orbhip.ComputeImageBounds(cam, w, h))
+        assert np.array_equal(oun["x"].view(np.uint32), gun["x"].view(np.uint32))
+        assert np.array_equal(ogs, ggs) and np.array_equal(ogi, ggi)

@@ -75,6 +75,7 @@ struct orbhip_extractor {
     int overlap = 0;               // ORBHIP_OVERLAP=1: FAST of level 0 runs beside the resize chain on aux_stream
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_l0 = nullptr, ev_f0 = nullptr;
+    hipEvent_t ev_busy = nullptr;    // end of the last extraction call: a call on another stream waits for it
     hipEvent_t ev_order = nullptr;   // orders work of another instance (stereo matching) against this one's stream
     hipStream_t last_stream = nullptr;   // stream of the last batch call
     int* d_status = nullptr;       // bit0 candidate overflow, bit1 output capacity
@@ -529,7 +530,8 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
               hipEventCreateWithFlags(&e->ev_l0, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&e->ev_f0, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&e->ev_busy, hipEventDisableTiming) == hipSuccess;
     for (Workspace& w : e->ws)
         ok = ok && hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&w.done, hipEventDisableTiming) == hipSuccess;
@@ -563,6 +565,7 @@ int orbhip_destroy(orbhip_extractor* e) {
     if (e->ev_f0) (void)hipEventDestroy(e->ev_f0);
     if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
     if (e->ev_order) (void)hipEventDestroy(e->ev_order);
+    if (e->ev_busy) (void)hipEventDestroy(e->ev_busy);
     delete e;
     return ORBHIP_OK;
 }
@@ -580,6 +583,10 @@ static int extract_device_impl(orbhip_extractor* e, const uint8_t* d_imgs, int n
     }
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    // A handle has one set of workspaces: a call on another stream than the previous one waits for
+    // that call's work before it touches them.
+    // (ev_busy was recorded at the end of that call, so the earlier stream itself is not touched again)
+    if (e->last_stream && e->last_stream != s) HIP_TRY(e, hipStreamWaitEvent(s, e->ev_busy, 0));
     e->last_stream = s;
     // frames per pass: max_batch, but keep the workspaces (about 20 bytes per input pixel and frame:
     // pyramid planes, FAST output segments, quadtree keys) under ~24 GB
@@ -619,6 +626,7 @@ static int extract_device_impl(orbhip_extractor* e, const uint8_t* d_imgs, int n
             HIP_TRY(e, hipEventRecord(e->ws[k].done, e->ws[k].stream));
             HIP_TRY(e, hipStreamWaitEvent(s, e->ws[k].done, 0));
         }
+    HIP_TRY(e, hipEventRecord(e->ev_busy, s));
     return ORBHIP_OK;
 }
 
@@ -661,8 +669,7 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
         e->d_in_bytes = need;
     }
     if (need > e->h_in_bytes) {
-        dfree(e->d_st_sad); dfree(e->d_st_rinfo); dfree(e->d_st_bins); dfree(e->d_st_tmp);
-    if (e->h_in) (void)hipHostFree(e->h_in);
+        if (e->h_in) (void)hipHostFree(e->h_in);
         e->h_in = nullptr; e->h_in_bytes = 0;
         HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_in), need, hipHostMallocDefault));
         e->h_in_bytes = need;
@@ -687,7 +694,8 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
     for (int f = 0; f < nframes; f++) {
         const uint8_t* src = imgs + (size_t)f * frame_stride;
         uint8_t* dst = e->h_in + (size_t)f * dev_frame;
-        if (row_stride == dev_row) std::memcpy(dst, src, dev_frame);
+        // (the caller owns width * channels bytes of every row, not the padding behind the last one)
+        if (row_stride == dev_row) std::memcpy(dst, src, (size_t)(height - 1) * row_stride + (size_t)width * channels);
         else for (int y = 0; y < height; y++) std::memcpy(dst + (size_t)y * dev_row, src + (size_t)y * row_stride, (size_t)width * channels);
     }
     HIP_TRY(e, hipMemcpyAsync(e->d_in, e->h_in, need, hipMemcpyHostToDevice, e->stream));
@@ -1196,17 +1204,18 @@ int orbhip_debug_sincos(orbhip_extractor* e, uint32_t first_bits, uint32_t count
 
 int orbhip_projection_level_mode(const float* Tcw_cur, const float* Tcw_last, float mb, int mono) {
     if (!Tcw_cur || !Tcw_last) return ORBHIP_ERR_ARG;
-    // twc = -Rcw^T tcw, tlc = Rlw twc + tlw (src/ORBmatcher.cc:1330-1335): CV_32F matrix products,
-    // accumulated in double and stored as float
+    // twc = -Rcw^T tcw, tlc = Rlw twc + tlw (src/ORBmatcher.cc:1330-1335): CV_32F matrix products; the
+    // transposed one goes through the general path (accumulated in double, stored as float)
     float twc[3];
     for (int r = 0; r < 3; r++) {
         double acc = 0;
         for (int k = 0; k < 3; k++) acc += (double)Tcw_cur[3 * k + r] * (double)Tcw_cur[9 + k];
         twc[r] = (float)(-acc);
     }
-    double acc = 0;
-    for (int k = 0; k < 3; k++) acc += (double)Tcw_last[6 + k] * (double)twc[k];
-    const float tlc_z = (float)(acc + (double)Tcw_last[11]);
+    // Rlw * twc + tlw has no transposed operand: the 3x3 by 3x1 product takes the small-matrix path
+    // like Rcw * x3Dw + tcw (float products summed in float, the addend added in double)
+    const float rz = Tcw_last[6] * twc[0] + Tcw_last[7] * twc[1] + Tcw_last[8] * twc[2];
+    const float tlc_z = (float)((double)rz + (double)Tcw_last[11]);
     if (mono) return 0;
     if (tlc_z > mb) return 1;                                  // bForward
     if (-tlc_z > mb) return 2;                                 // bBackward
