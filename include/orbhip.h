@@ -177,6 +177,25 @@ int orbhip_stereo_match_batch_device(orbhip_extractor* left, orbhip_extractor* r
                                      const orbhip_keypoint* d_kp_r, const uint8_t* d_desc_r, const int* d_cnt_r,
                                      int cap, float mb, float mbf, float* d_uright, float* d_depth, int* d_nmatch,
                                      void* stream);
+
+/* The same matching for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): it has no counterpart in the reference. Arguments and
+ * results are those of orbhip_stereo_match_batch_device; the kernels are the same. Its scratch
+ * (right-image records, per-keypoint SAD values, row-bin offsets: about 10.6 MB) is a static array in
+ * the library's device image, one copy per GPU, whose address is taken once per device when a
+ * handle is created there; the call itself allocates and frees nothing. Batches beyond the limits
+ * below are refused with ORBHIP_ERR_CAPACITY. All calls on one GPU share that GPU's array (the
+ * kernels overwrite every element they read, nothing has to be cleared between calls): calls that
+ * overlap in time on one GPU race, also from different handles or streams. Per-kernel timing
+ * (orbhip_enable_timing) does not cover this call. */
+#define ORBHIP_NOALLOC_MAX_PAIRS 4096              /* nframes */
+#define ORBHIP_NOALLOC_MAX_SLOTS (1 << 19)         /* nframes * cap */
+#define ORBHIP_NOALLOC_MAX_BIN_ENTRIES (1 << 17)   /* nframes * ((image height >> 4) + 3) */
+int orbhip_stereo_match_batch_device_noalloc(orbhip_extractor* left, orbhip_extractor* right, int nframes,
+                                     const orbhip_keypoint* d_kp_l, const uint8_t* d_desc_l, const int* d_cnt_l,
+                                     const orbhip_keypoint* d_kp_r, const uint8_t* d_desc_r, const int* d_cnt_r,
+                                     int cap, float mb, float mbf, float* d_uright, float* d_depth, int* d_nmatch,
+                                     void* stream);
 /* The same for one pair with host arrays (the last orbhip_extract of each instance): kp/desc as
  * returned by orbhip_extract, uright / depth receive n_l floats. Waits for the result. */
 int orbhip_stereo_match(orbhip_extractor* left, orbhip_extractor* right,

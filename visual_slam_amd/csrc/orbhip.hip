@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -53,6 +54,37 @@ const int kMinLaneFrames = 16;     // batches below twice this run as one pass o
 
 } // namespace
 
+// Scratch of orbhip_stereo_match_batch_device_noalloc: the right-image records (16 bytes per keypoint
+// slot), the SAD of every left keypoint's match plus one spare counter per pair (4 bytes per slot),
+// and the row-bin offsets. It lives in the library's device image, so every GPU the library runs on
+// holds its own copy at its own address until the process ends; the name below is only the host-side
+// stand-in of the symbol: host code uses the address hipGetSymbolAddress reports for the current
+// device (noalloc_scratch_ptr), never the name.
+#define NOALLOC_SAD_BYTES ((size_t)(ORBHIP_NOALLOC_MAX_SLOTS + ORBHIP_NOALLOC_MAX_PAIRS) * sizeof(int))
+#define NOALLOC_RINFO_BYTES ((size_t)ORBHIP_NOALLOC_MAX_SLOTS * sizeof(int4))
+#define NOALLOC_BINS_BYTES ((size_t)ORBHIP_NOALLOC_MAX_BIN_ENTRIES * sizeof(int))
+static __device__ __align__(256) unsigned char scratch[NOALLOC_RINFO_BYTES + NOALLOC_SAD_BYTES + NOALLOC_BINS_BYTES];
+
+namespace {
+const int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kMaxDevices] = {nullptr};   // device address of `scratch` on every device seen so far
+
+// Address of `scratch` on `device` (which must be the current device), resolved once per device.
+hipError_t noalloc_scratch_ptr(int device, void** out) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t st = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (st != hipSuccess) return st;
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+} // namespace
+
 struct orbhip_extractor {
     orbhip_params prm;
     double scale_factor_d;
@@ -79,6 +111,7 @@ struct orbhip_extractor {
     hipEvent_t ev_order = nullptr;   // orders work of another instance (stereo matching) against this one's stream
     hipStream_t last_stream = nullptr;   // stream of the last batch call
     int* d_status = nullptr;       // bit0 candidate overflow, bit1 output capacity
+    void* noalloc_scratch = nullptr;   // address of the library's static scratch on this handle's device
     float* d_map_x = nullptr;      // rectification maps (orbhip_set_rectification), map_w x map_h floats each
     float* d_map_y = nullptr;
     int map_w = 0, map_h = 0;
@@ -526,6 +559,8 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
         delete e;
         return ORBHIP_ERR_HIP;
     }
+    // the static scratch of the no-allocation entry point: its address on this device, taken once per device
+    if (noalloc_scratch_ptr(e->device, &e->noalloc_scratch) != hipSuccess) { orbhip_destroy(e); return ORBHIP_ERR_HIP; }
     bool ok = hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&e->ev_l0, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&e->ev_f0, hipEventDisableTiming) == hipSuccess &&
@@ -874,11 +909,11 @@ int orbhip_get_timing(orbhip_extractor* e, const char** names, float* ms, int* l
     return KC_COUNT;
 }
 
-int orbhip_stereo_match_batch_device(orbhip_extractor* left, orbhip_extractor* right, int nframes,
-                                     const orbhip_keypoint* d_kp_l, const uint8_t* d_desc_l, const int* d_cnt_l,
-                                     const orbhip_keypoint* d_kp_r, const uint8_t* d_desc_r, const int* d_cnt_r,
-                                     int cap, float mb, float mbf, float* d_uright, float* d_depth, int* d_nmatch,
-                                     void* stream) {
+// Argument and state checks shared by the two batch entry points of the stereo matching.
+static int stereo_batch_check(orbhip_extractor* left, orbhip_extractor* right, int nframes,
+                              const orbhip_keypoint* d_kp_l, const uint8_t* d_desc_l, const int* d_cnt_l,
+                              const orbhip_keypoint* d_kp_r, const uint8_t* d_desc_r, const int* d_cnt_r,
+                              int cap, float mb, const float* d_uright, const float* d_depth) {
     if (!left || !right || !d_kp_l || !d_desc_l || !d_cnt_l || !d_kp_r || !d_desc_r || !d_cnt_r || !d_uright || !d_depth ||
         cap < 1 || cap > 65535 || nframes < 1 || !(mb > 0.f))
         return ORBHIP_ERR_ARG;
@@ -892,31 +927,33 @@ int orbhip_stereo_match_batch_device(orbhip_extractor* left, orbhip_extractor* r
         e->err = "left and right instances differ in device, image size or pyramid parameters";
         return ORBHIP_ERR_ARG;
     }
-    HIP_TRY(e, hipSetDevice(e->device));
-    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
-    const size_t need = (size_t)nframes * cap + (size_t)nframes;   // + a counter per frame when the caller wants none
-    if (need > e->d_st_sad_n) {
-        HIP_TRY(e, hipDeviceSynchronize());
-        dfree(e->d_st_sad); dfree(e->d_st_rinfo);
-        HIP_TRY(e, hipMalloc(&e->d_st_sad, need * sizeof(int)));
-        HIP_TRY(e, hipMalloc(&e->d_st_rinfo, (size_t)nframes * cap * sizeof(int4)));
-        e->d_st_sad_n = need;
-    }
-    // row bins of the right keypoints; a row band is at most 2 * ceil(2 * scale) + 2 rows high
-    const int nbins = (left->plan.lv[0].h >> ST_BIN_SHIFT) + 2;
-    const int band = 2 * (int)std::ceil(2.0f * left->sf.back()) + 2;
-    if ((size_t)nframes * (nbins + 1) > e->d_st_bins_n) {
-        HIP_TRY(e, hipDeviceSynchronize());
-        dfree(e->d_st_bins);
-        HIP_TRY(e, hipMalloc(&e->d_st_bins, (size_t)nframes * (nbins + 1) * sizeof(int)));
-        e->d_st_bins_n = (size_t)nframes * (nbins + 1);
-    }
     // the level geometry of the two plans is the same function of (size, parameters); plane
     // offsets depend on the frames a plan was made for, so each side is addressed with its own plan
     if (left->plan_frames != right->plan_frames) {
         e->err = "left and right instances must be used with the same pass size";
         return ORBHIP_ERR_ARG;
     }
+    return ORBHIP_OK;
+}
+
+// Row bins of the right keypoints: bins per frame, and the height of a row band (at most
+// 2 * ceil(2 * scale) + 2 rows).
+static void stereo_bins(const orbhip_extractor* left, int* nbins, int* band) {
+    *nbins = (left->plan.lv[0].h >> ST_BIN_SHIFT) + 2;
+    *band = 2 * (int)std::ceil(2.0f * left->sf.back()) + 2;
+}
+
+// The three launches of the stereo matching on scratch buffers the caller of this function chose:
+// sad [nframes * cap + nframes] ints, rinfo [nframes * cap] records, bins [nframes * (nbins + 1)] ints.
+// The kernels write every scratch element before they read it: nothing has to be cleared.
+static int stereo_batch_launch(orbhip_extractor* left, orbhip_extractor* right, int nframes,
+                               const orbhip_keypoint* d_kp_l, const uint8_t* d_desc_l, const int* d_cnt_l,
+                               const orbhip_keypoint* d_kp_r, const uint8_t* d_desc_r, const int* d_cnt_r,
+                               int cap, float mb, float mbf, float* d_uright, float* d_depth, int* d_nmatch,
+                               hipStream_t s, int* sad, int4* rinfo, int* bins, bool timed) {
+    orbhip_extractor* e = left;
+    int nbins, band;
+    stereo_bins(left, &nbins, &band);
     // the two extractions may have run on other streams than `s`: wait for them here, and make their
     // streams wait for the matching before a later pass overwrites the pyramids it reads
     orbhip_extractor* const sides[2] = {left, right};
@@ -925,22 +962,24 @@ int orbhip_stereo_match_batch_device(orbhip_extractor* left, orbhip_extractor* r
             HIP_TRY(e, hipEventRecord(x->ev_order, x->last_stream));
             HIP_TRY(e, hipStreamWaitEvent(s, x->ev_order, 0));
         }
-    {
-    SpanGuard t(e, s, KC_STEREO);
-    hipLaunchKernelGGL(k_stereo_prep, dim3(nframes), dim3(256), 0, s,
-                       left->d_plan, reinterpret_cast<const StKp*>(d_kp_r), d_cnt_r, cap, nbins, e->d_st_rinfo, e->d_st_bins);
     const int ngroups = (cap + 3) / 4;                         // 4 left keypoints per workgroup
     const unsigned nwg = (unsigned)ngroups * 8u * (unsigned)((nframes + 7) / 8);
     if ((unsigned long long)nwg * (8ull * ngroups) >= (1ull << 32)) { e->err = "too many keypoints per pass"; return ORBHIP_ERR_CAPACITY; }
+    const bool was_timing = e->timing;
+    if (!timed) e->timing = false;                             // the timing spans take events from a pool that may have to grow
+    {
+    SpanGuard t(e, s, KC_STEREO);
+    hipLaunchKernelGGL(k_stereo_prep, dim3(nframes), dim3(256), 0, s,
+                       left->d_plan, reinterpret_cast<const StKp*>(d_kp_r), d_cnt_r, cap, nbins, rinfo, bins);
     hipLaunchKernelGGL(k_stereo_match, dim3(nwg), dim3(256), 0, s,
-                       left->d_plan, e->d_st_rinfo, e->d_st_bins, nbins, band, left->ws[left->last_ws].d_pyr, right->ws[right->last_ws].d_pyr,
+                       left->d_plan, rinfo, bins, nbins, band, left->ws[left->last_ws].d_pyr, right->ws[right->last_ws].d_pyr,
                        reinterpret_cast<const StKp*>(d_kp_l), d_desc_l, d_cnt_l,
-                       reinterpret_cast<const StKp*>(d_kp_r), d_desc_r, cap, mb, mbf, d_uright, d_depth, e->d_st_sad,
+                       reinterpret_cast<const StKp*>(d_kp_r), d_desc_r, cap, mb, mbf, d_uright, d_depth, sad,
                        nframes, ngroups, grid_magic(8u * (unsigned)ngroups));
-    int* nm = d_nmatch;
-    hipLaunchKernelGGL(k_stereo_median, dim3(nframes), dim3(256), 0, s, d_cnt_l, cap, e->d_st_sad, d_uright, d_depth,
-                       nm ? nm : e->d_st_sad + (size_t)nframes * cap);
+    hipLaunchKernelGGL(k_stereo_median, dim3(nframes), dim3(256), 0, s, d_cnt_l, cap, sad, d_uright, d_depth,
+                       d_nmatch ? d_nmatch : sad + (size_t)nframes * cap);
     }
+    e->timing = was_timing;
     HIP_TRY(e, hipGetLastError());
     for (orbhip_extractor* x : sides)
         if (x->last_stream && x->last_stream != s) {
@@ -948,6 +987,65 @@ int orbhip_stereo_match_batch_device(orbhip_extractor* left, orbhip_extractor* r
             HIP_TRY(e, hipStreamWaitEvent(x->last_stream, x->ev_order, 0));
         }
     return ORBHIP_OK;
+}
+
+int orbhip_stereo_match_batch_device(orbhip_extractor* left, orbhip_extractor* right, int nframes,
+                                     const orbhip_keypoint* d_kp_l, const uint8_t* d_desc_l, const int* d_cnt_l,
+                                     const orbhip_keypoint* d_kp_r, const uint8_t* d_desc_r, const int* d_cnt_r,
+                                     int cap, float mb, float mbf, float* d_uright, float* d_depth, int* d_nmatch,
+                                     void* stream) {
+    int rc = stereo_batch_check(left, right, nframes, d_kp_l, d_desc_l, d_cnt_l, d_kp_r, d_desc_r, d_cnt_r, cap, mb, d_uright, d_depth);
+    if (rc) return rc;
+    orbhip_extractor* e = left;
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    const size_t need = (size_t)nframes * cap + (size_t)nframes;   // + a counter per frame when the caller wants none
+    if (need > e->d_st_sad_n) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        dfree(e->d_st_sad); dfree(e->d_st_rinfo);
+        e->d_st_sad_n = 0;
+        HIP_TRY(e, hipMalloc(&e->d_st_sad, need * sizeof(int)));
+        HIP_TRY(e, hipMalloc(&e->d_st_rinfo, (size_t)nframes * cap * sizeof(int4)));
+        e->d_st_sad_n = need;
+    }
+    int nbins, band;
+    stereo_bins(left, &nbins, &band);
+    if ((size_t)nframes * (nbins + 1) > e->d_st_bins_n) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        dfree(e->d_st_bins);
+        e->d_st_bins_n = 0;
+        HIP_TRY(e, hipMalloc(&e->d_st_bins, (size_t)nframes * (nbins + 1) * sizeof(int)));
+        e->d_st_bins_n = (size_t)nframes * (nbins + 1);
+    }
+    return stereo_batch_launch(left, right, nframes, d_kp_l, d_desc_l, d_cnt_l, d_kp_r, d_desc_r, d_cnt_r, cap, mb, mbf,
+                               d_uright, d_depth, d_nmatch, s, e->d_st_sad, e->d_st_rinfo, e->d_st_bins, true);
+}
+
+int orbhip_stereo_match_batch_device_noalloc(orbhip_extractor* left, orbhip_extractor* right, int nframes,
+                                             const orbhip_keypoint* d_kp_l, const uint8_t* d_desc_l, const int* d_cnt_l,
+                                             const orbhip_keypoint* d_kp_r, const uint8_t* d_desc_r, const int* d_cnt_r,
+                                             int cap, float mb, float mbf, float* d_uright, float* d_depth, int* d_nmatch,
+                                             void* stream) {
+    int rc = stereo_batch_check(left, right, nframes, d_kp_l, d_desc_l, d_cnt_l, d_kp_r, d_desc_r, d_cnt_r, cap, mb, d_uright, d_depth);
+    if (rc) return rc;
+    orbhip_extractor* e = left;
+    int nbins, band;
+    stereo_bins(left, &nbins, &band);
+    if (nframes > ORBHIP_NOALLOC_MAX_PAIRS || (unsigned long long)nframes * cap > ORBHIP_NOALLOC_MAX_SLOTS ||
+        (unsigned long long)nframes * (nbins + 1) > ORBHIP_NOALLOC_MAX_BIN_ENTRIES) {
+        e->err = "batch too large for the static scratch of the no-allocation entry point (ORBHIP_NOALLOC_MAX_* in orbhip.h)";
+        return ORBHIP_ERR_CAPACITY;
+    }
+    if (!e->noalloc_scratch) { e->err = "static scratch address unknown"; return ORBHIP_ERR_STATE; }
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    // carve the device's copy of the static array (its address, not the symbol's name)
+    unsigned char* base = static_cast<unsigned char*>(e->noalloc_scratch);
+    int4* rinfo = reinterpret_cast<int4*>(base);
+    int* sad = reinterpret_cast<int*>(base + NOALLOC_RINFO_BYTES);
+    int* bins = reinterpret_cast<int*>(base + NOALLOC_RINFO_BYTES + NOALLOC_SAD_BYTES);
+    return stereo_batch_launch(left, right, nframes, d_kp_l, d_desc_l, d_cnt_l, d_kp_r, d_desc_r, d_cnt_r, cap, mb, mbf,
+                               d_uright, d_depth, d_nmatch, s, sad, rinfo, bins, false);
 }
 
 int orbhip_stereo_match(orbhip_extractor* left, orbhip_extractor* right,
