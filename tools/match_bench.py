@@ -120,7 +120,7 @@ def main():
             t += time.perf_counter() - t0
             ok = ok and on == hn[i] and np.array_equal(om, hm[i, :hc2[i]])
         out["oracle_parity_first_pairs"] = bool(ok)
-        out["cpu_oracle_pairs_per_s_one_thread"] = round(m / t, 1)
+        if m > 0: out["cpu_oracle_pairs_per_s_one_thread"] = round(m / t, 1)
     except ImportError:
         pass
     print(json.dumps(out))
@@ -177,7 +177,7 @@ def main():
             t += time.perf_counter() - t0
             ok = ok and on == hn[i] and np.array_equal(om, hm[i, :hc2[i]])
         out["oracle_parity_first_frames"] = bool(ok)
-        out["cpu_oracle_frames_per_s_one_thread"] = round(m / t, 1)
+        if m > 0: out["cpu_oracle_frames_per_s_one_thread"] = round(m / t, 1)
     except ImportError:
         pass
     print(json.dumps(out))
@@ -222,7 +222,7 @@ def main():
             t += time.perf_counter() - t0
             ok = ok and on == hn[i] and np.array_equal(om, hm[i, :hc2[i]])
         out["oracle_parity_first_pairs"] = bool(ok)
-        out["cpu_oracle_pairs_per_s_one_thread"] = round(m / t, 1)
+        if m > 0: out["cpu_oracle_pairs_per_s_one_thread"] = round(m / t, 1)
     except ImportError:
         pass
     print(json.dumps(out))
