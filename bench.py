@@ -5,11 +5,14 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" is one full extraction pass (pyramid, FAST + quadtree, orientation, blur + rBRIEF) over
-a batch of synthetic 1920x1080 frames that already sit in HBM (workload C4: 2000 features,
-8 levels, scale 1.2, FAST 20/7). With N GPUs every rank owns its own batch of the same size (weak
-scaling, frames are independent, no data-path collective); the job value is total frames / max
-rank time. Rank 0 prints one JSON line.
+One "step" is one full extraction (pyramid, FAST + quadtree, orientation, blur + rBRIEF) of a batch
+of synthetic 1920x1080 frames that already sit in HBM (workload C4: 2000 features, 8 levels, scale
+1.2, FAST 20/7; 1024 frames per GPU and step, which the library runs as two passes of 512). Frames
+are independent: every rank owns a contiguous range of them and no collective runs on the data path;
+the job value is total frames / max rank time. Rank 0 prints one JSON line.
+  --scaling weak   (default) every rank extracts --batch frames per step
+  --scaling strong the job's --total-batch frames (or pairs) are cut into one contiguous range per rank
+  --preset c4_strong_1024 / c3_stereo_512 : the two sharded configurations of BASELINE.json by name
 
 The line also carries
   roofline     : the kernel class with the largest device time, its algorithmic bytes per launch
@@ -31,6 +34,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+VALU_CYCLES_PER_INST = 4.25   # measured issue cost of the instruction kinds the kernels use (profiles/r02_valu_calib.txt)
 
 WORKLOADS = {
     # name: (w, h, nfeatures, scale, levels, iniTh, minTh)
@@ -118,11 +122,12 @@ def profiled_valu(kernel, frames):
         return None, None
 
 
-def make_batch_on_device(torch, kind, w, h, nframes, device, nbase=16):
-    """nbase host-generated frames, expanded on the device by distinct circular shifts."""
+def make_batch_on_device(torch, kind, w, h, nframes, device, nbase=16, start=0):
+    """nbase host-generated frames (synthetic frame indices from `start` on), expanded on the device by
+    distinct circular shifts."""
     from visual_slam_amd import synth
     nbase = min(nbase, nframes)
-    base = torch.from_numpy(synth.batch(kind, w, h, nbase)).to(device)
+    base = torch.from_numpy(synth.batch(kind, w, h, nbase, start)).to(device)
     out = torch.empty((nframes, h, w), dtype=torch.uint8, device=device)
     for i in range(nframes):
         b, k = i % nbase, i // nbase
@@ -135,7 +140,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="frames (pairs with --stereo) per GPU per step in weak scaling")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch frames per GPU; strong: --total-batch frames over all GPUs (contiguous range per rank)")
+    ap.add_argument("--total-batch", type=int, default=1024, help="frames (pairs with --stereo) per step of the whole job in strong scaling")
+    ap.add_argument("--preset", default=None, choices=["c4_strong_1024", "c3_stereo_512"],
+                    help="c4_strong_1024: 1024 1080p frames per step over all GPUs; c3_stereo_512: 512 EuRoC-shaped stereo pairs per step over all GPUs")
     ap.add_argument("--max-batch", type=int, default=0, help="frames per internal pass (0 = library default)")
     ap.add_argument("--workload", default="C4_1080p_2000f", choices=sorted(WORKLOADS))
     ap.add_argument("--kind", default="blocks", choices=["blocks", "noise", "lowc"])
@@ -148,6 +158,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for the barrier / max-time reduction")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses GPU 0 (use with --backend gloo)")
     args = ap.parse_args()
+    if args.preset == "c4_strong_1024":
+        args.workload, args.scaling, args.total_batch, args.stereo = "C4_1080p_2000f", "strong", 1024, False
+    elif args.preset == "c3_stereo_512":
+        args.workload, args.scaling, args.total_batch, args.stereo = "C3_euroc", "strong", 512, True
 
     import torch
     from visual_slam_amd import orbhip, synth
@@ -178,8 +192,17 @@ def main():
     cap = ex.max_keypoints()
     if args.rectify:
         ex.set_rectification(*synth.rectify_maps(w, h))
-    B = args.batch
-    frames = make_batch_on_device(torch, args.kind, w, h, B, device)
+    if args.scaling == "strong":
+        from visual_slam_amd import sharding
+        lo, hi = sharding.shard_range(args.total_batch, world, rank)     # a unit is a frame, or a pair with --stereo
+        B = hi - lo
+        if B < 1:
+            sys.exit("--total-batch %d leaves rank %d without work" % (args.total_batch, rank))
+        job_units = args.total_batch
+    else:
+        B = args.batch
+        job_units = world * B
+    frames = make_batch_on_device(torch, args.kind, w, h, B, device, start=16 * rank)   # every rank its own frames
     d_kp = torch.empty((B, cap, 7), dtype=torch.float32, device=device)
     d_desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=device)
     d_cnt = torch.zeros((B,), dtype=torch.int32, device=device)
@@ -201,18 +224,19 @@ def main():
         frames_c = frames.unsqueeze(-1).expand(B, h, w, args.color).contiguous()
 
     def step():
+        if args.stereo:
+            # both extractions and the matching, pass by pass inside the library (any batch size)
+            orbhip.extract_stereo_batch_device(ex, exr, frames.data_ptr(), frames_r.data_ptr(), B, w, h, w, w * h,
+                                               d_kp.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(),
+                                               r_kp.data_ptr(), r_desc.data_ptr(), r_cnt.data_ptr(), cap, bf / fx, bf,
+                                               d_ur.data_ptr(), d_dep.data_ptr(), d_nm.data_ptr(), stream.cuda_stream)
+            return
         if args.color:
             ex.extract_batch_device_color(frames_c.data_ptr(), B, w, h, w * args.color, w * h * args.color, args.color, 0,
                                           d_kp.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(), cap, stream.cuda_stream)
         else:
             ex.extract_batch_device(frames.data_ptr(), B, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(),
                                     d_cnt.data_ptr(), cap, stream.cuda_stream)
-        if args.stereo:
-            exr.extract_batch_device(frames_r.data_ptr(), B, w, h, w, w * h, r_kp.data_ptr(), r_desc.data_ptr(),
-                                     r_cnt.data_ptr(), cap, stream.cuda_stream)
-            orbhip.stereo_match_batch_device(ex, exr, B, d_kp.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(),
-                                             r_kp.data_ptr(), r_desc.data_ptr(), r_cnt.data_ptr(), cap, bf / fx, bf,
-                                             d_ur.data_ptr(), d_dep.data_ptr(), d_nm.data_ptr(), stream.cuda_stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -246,7 +270,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    fps = world * B * args.steps / dt
+    fps = job_units * args.steps / dt
 
     if rank == 0:
         counts = d_cnt.cpu().numpy()
@@ -276,18 +300,23 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": int(k_bytes_per_launch), "avg_launch_ms": round(k_avg_s * 1e3, 4),
                     "whole_path_bytes_per_frame": int(total_bytes),
-                    "whole_path_frac": round(fps / world * total_bytes / 1e9 / HBM_PEAK_GBS, 4),
+                    "whole_path_frac": round(B * args.steps / dt * total_bytes / 1e9 / HBM_PEAK_GBS, 4),
                     "compulsory_bytes_per_frame": int(compulsory_bytes(w, h, scale, levels, nfeat)),
                     "device_copy_GBs": round(copy_gbs, 1),
-                    "whole_path_frac_of_copy": round(fps / world * total_bytes / 1e9 / copy_gbs, 4),
+                    "whole_path_frac_of_copy": round(B * args.steps / dt * total_bytes / 1e9 / copy_gbs, 4),
                     "frames_per_pass": int(frames_per_launch), "passes_in_flight": lanes,
                     "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in timing.items()}}
-        # the limit that actually binds the dominant kernel: vector-ALU issue. A wave64 instruction
-        # holds one of the 1024 SIMDs for 4 cycles; the rate below is at the 2.4 GHz peak clock.
+        # the limit that actually binds the dominant kernel: vector-ALU issue. Measured on this chip
+        # (tools/calib/valu_calib.hip, profiles/r02_valu_calib.txt): with 2..8 waves per SIMD a SIMD needs
+        # 4.25 cycles per wave64 instruction for packed 16-bit, 3-operand, DPP, SDWA, multiply and
+        # compare instructions (what these kernels are made of) and 2.2 for plain 32-bit add / sub /
+        # and / or / shift-right / move streams. The fraction below prices every instruction at 4.25 cycles
+        # at the 2.4 GHz peak clock.
         valu, valu_src = profiled_valu(kname, frames_per_launch) if profiled else (None, None)
         if valu:
-            peak_rate = 256 * 4 / 4.0 * 2.4e9
+            peak_rate = 256 * 4 / VALU_CYCLES_PER_INST * 2.4e9
             roofline["valu"] = {"wave_insts_per_launch": valu, "source": valu_src, "achieved_insts_per_s": round(valu / k_avg_s, 1),
+                                "cycles_per_inst_calibrated": VALU_CYCLES_PER_INST, "calibration": "profiles/r02_valu_calib.txt",
                                 "peak_insts_per_s": peak_rate, "frac": round(valu / k_avg_s / peak_rate, 4)}
         # with several passes in flight (ORBHIP_LANES > 1) also time the same kernels one at a time (a
         # second handle limited to one pass, two untimed steps): a kernel with the GPU to itself
@@ -326,8 +355,9 @@ def main():
             if args.stereo:
                 # pairs dealt to worker threads (ctypes releases the GIL), each with its own two oracle instances
                 from concurrent.futures import ThreadPoolExecutor
-                npairs = max(args.cpu_frames // 2, 1)
-                pairs = [synth.stereo_pair(args.kind, w, h, i, (12,)) for i in range(npairs)]
+                npairs = max(min(args.cpu_frames // 2, B), 1)
+                hl, hr = frames[:npairs].cpu().numpy(), frames_r[:npairs].cpu().numpy()   # the first pairs of the GPU batch
+                pairs = list(zip(hl, hr))
                 prm = (nfeat, scale, levels, ini_th, min_th)
 
                 def work(t):
@@ -341,12 +371,15 @@ def main():
                     list(pool.map(work, range(nthreads)))
                 secs = time.perf_counter() - t1
                 cpu = {"value": round(npairs / secs, 2), "unit": "pairs/s", "cores": nthreads, "kind": "port",
-                       "sample": "%d %s pairs of %s, two oracle instances per thread" % (npairs, args.kind, args.workload)}
+                       "sample": "the first %d of the %d %s pairs of %s the GPU step extracts, two oracle instances per thread" % (npairs, B, args.kind, args.workload)}
             else:
-                sample = synth.batch(args.kind, w, h, args.cpu_frames)
+                ncpu = min(args.cpu_frames, B)
+                sample = frames[:ncpu].cpu().numpy()     # the first frames of the very batch the GPU steps extract
                 secs, ccounts = orb_oracle.extract_batch_mt((nfeat, scale, levels, ini_th, min_th), sample, nthreads)
-                cpu = {"value": round(args.cpu_frames / secs, 2), "unit": "frames/s", "cores": nthreads, "kind": "port",
-                       "sample": "%d %s frames of %s, one oracle instance per thread" % (args.cpu_frames, args.kind, args.workload)}
+                same = bool(np.array_equal(ccounts, counts[:ncpu]))
+                cpu = {"value": round(ncpu / secs, 2), "unit": "frames/s", "cores": nthreads, "kind": "port",
+                       "sample": "the first %d of the %d %s frames of %s the GPU step extracts, one oracle instance per thread" % (ncpu, B, args.kind, args.workload),
+                       "keypoint_counts_equal_gpu": same}
         extra = {}
         if args.host_fed:
             host = frames[:min(B, 64)].cpu().numpy()
@@ -358,10 +391,10 @@ def main():
             "metric": ("ORB extract + stereo match pairs/s" if args.stereo else
                        "ORB extract frames/s (1080p, 2k feats)" if args.workload == "C4_1080p_2000f" else "ORB extract frames/s"),
             "value": round(fps, 1), "unit": "pairs/s" if args.stereo else "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": args.workload, "image": [w, h], "nfeatures": nfeat, "levels": levels, "scale": scale,
-                       "fast_th": [ini_th, min_th], "frames_per_gpu_per_step": B, "distribution": args.kind,
+                       "fast_th": [ini_th, min_th], "frames_per_gpu_per_step": B, "frames_per_step": job_units, "distribution": args.kind,
                        "inputs": "device-resident" + (", %d-channel BGR" % args.color if args.color else "") + (", rectified by remap" if args.rectify else ""), "pyramid_copied_back": False, "blur_variant": "legacy",
                        "mean_keypoints_per_frame": round(n_out, 1), "sharding": "frames, no collective",
                        **({"stereo": True, "mean_matches_per_pair": round(float(d_nm.float().mean().item()), 1)} if args.stereo else {})},

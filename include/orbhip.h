@@ -196,6 +196,19 @@ int orbhip_stereo_match_batch_device_noalloc(orbhip_extractor* left, orbhip_extr
                                      const orbhip_keypoint* d_kp_r, const uint8_t* d_desc_r, const int* d_cnt_r,
                                      int cap, float mb, float mbf, float* d_uright, float* d_depth, int* d_nmatch,
                                      void* stream);
+/* Extraction of both images of `nframes` rectified pairs and their stereo matching in one call: what the
+ * stereo constructor of Frame does per pair (two ExtractORB calls, src/Frame.cc:114-117, then
+ * ComputeStereoMatches, src/Frame.cc:481-653), for a device-resident batch of any size. A batch larger than
+ * one internal pass is processed pass by pass (left pass, right pass, matching of those pairs), so the
+ * matcher always finds the pyramids of the pairs it works on. Gray images, both sides with the same size
+ * and strides; outputs as in orbhip_extract_batch_device (both sides) and orbhip_stereo_match_batch_device.
+ * Asynchronous on `stream` (NULL = left's own stream). */
+int orbhip_extract_stereo_batch_device(orbhip_extractor* left, orbhip_extractor* right,
+                                       const uint8_t* d_imgs_l, const uint8_t* d_imgs_r, int nframes, int width, int height,
+                                       size_t row_stride, size_t frame_stride,
+                                       orbhip_keypoint* d_kp_l, uint8_t* d_desc_l, int* d_cnt_l,
+                                       orbhip_keypoint* d_kp_r, uint8_t* d_desc_r, int* d_cnt_r, int cap,
+                                       float mb, float mbf, float* d_uright, float* d_depth, int* d_nmatch, void* stream);
 /* The same for one pair with host arrays (the last orbhip_extract of each instance): kp/desc as
  * returned by orbhip_extract, uright / depth receive n_l floats. Waits for the result. */
 int orbhip_stereo_match(orbhip_extractor* left, orbhip_extractor* right,

@@ -24,6 +24,9 @@ CONFIGS = {
     "mono_init_2x": (640, 480, 2000, 1.2, 8, 20, 7),     # monocular initialisation uses 2*nFeatures (src/Tracking.cc:123)
     "scale_2_0": (800, 600, 800, 2.0, 4, 20, 7),
     "one_level": (320, 240, 300, 1.2, 1, 20, 7),
+    # quotas beyond what the quadtree's node arrays can hold in LDS (~2000 per level): they spill to global memory
+    "one_level_3000": (640, 480, 3000, 1.2, 1, 20, 7),
+    "two_levels_9000": (1241, 376, 9000, 1.2, 2, 20, 7),
 }
 
 
@@ -59,7 +62,8 @@ def test_stages_and_outputs(mods, name, kind):
     print(name, kind, {k: v for k, v in r.items() if k != "desc_bad"})
 
 
-@pytest.mark.parametrize("name", ["C4_1080p", "kitti_th12", "C5_4k_deep", "mono_init_2x", "scale_2_0", "one_level"])
+@pytest.mark.parametrize("name", ["C4_1080p", "kitti_th12", "C5_4k_deep", "mono_init_2x", "scale_2_0", "one_level", "one_level_3000",
+                                  "two_levels_9000"])
 def test_outputs_large(mods, name):
     cfg = CONFIGS[name]
     g, o = _pair(mods, cfg)

@@ -134,3 +134,43 @@ def test_one_pair_of_instances_across_input_sizes():
         gun, ggs, ggi = orbhip.UndistortAndAssignToGrid(gL, gkl, cam, orbhip.ComputeImageBounds(cam, w, h))
         assert np.array_equal(oun["x"].view(np.uint32), gun["x"].view(np.uint32))
         assert np.array_equal(ogs, ggs) and np.array_equal(ogi, ggi)
+
+
+def test_extract_and_match_in_one_call_across_passes():
+    """orbhip_extract_stereo_batch_device on 5 pairs with passes of 2: extraction and matching run pass by pass,
+    every pair's outputs equal the oracle's; the plain matcher call on more pairs than a pass holds is refused."""
+    import torch
+    from oracle import orb_oracle as O
+    from visual_slam_amd import orbhip
+    w, h, prm, n = 640, 480, (1000, 1.2, 8, 20, 7), 5
+    pairs = [synth.stereo_pair("blocks", w, h, 20 + i, (4, 17)) for i in range(n)]
+    dev = torch.device("cuda", 0)
+    L = torch.from_numpy(np.stack([p[0] for p in pairs])).to(dev)
+    R = torch.from_numpy(np.stack([p[1] for p in pairs])).to(dev)
+    gL, gR = orbhip.ORBextractor(*prm, max_batch=2), orbhip.ORBextractor(*prm, max_batch=2)
+    cap = gL.max_keypoints()
+    mk = lambda: (torch.empty((n, cap, 7), dtype=torch.float32, device=dev), torch.empty((n, cap, 32), dtype=torch.uint8, device=dev),
+                  torch.zeros((n,), dtype=torch.int32, device=dev))
+    (kl, dl, cl), (kr, dr, cr) = mk(), mk()
+    ur = torch.empty((n, cap), dtype=torch.float32, device=dev)
+    dp = torch.empty((n, cap), dtype=torch.float32, device=dev)
+    nm = torch.zeros((n,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    orbhip.extract_stereo_batch_device(gL, gR, L.data_ptr(), R.data_ptr(), n, w, h, w, w * h, kl.data_ptr(), dl.data_ptr(), cl.data_ptr(),
+                                       kr.data_ptr(), dr.data_ptr(), cr.data_ptr(), cap, BF / FX, BF, ur.data_ptr(), dp.data_ptr(), nm.data_ptr())
+    gL.synchronize(); gR.synchronize()
+    torch.cuda.synchronize()
+    for i, (left, right) in enumerate(pairs):
+        oL, oR = O.OracleExtractor(*prm), O.OracleExtractor(*prm)
+        okl, odl = oL.extract(left)
+        okr, odr = oR.extract(right)
+        ou, od, on = O.stereo_match(oL, oR, okl, odl, okr, odr, BF / FX, BF)
+        k = int(cl[i].item())
+        assert k == len(okl) and int(cr[i].item()) == len(okr) and int(nm[i].item()) == on
+        assert np.array_equal(kl[i, :k, 0].cpu().numpy(), okl["x"]) and np.array_equal(dl[i, :k].cpu().numpy(), odl)
+        assert np.array_equal(ur[i, :k].cpu().numpy().view(np.uint32), ou.view(np.uint32))
+        assert np.array_equal(dp[i, :k].cpu().numpy().view(np.uint32), od.view(np.uint32))
+    with pytest.raises(orbhip.OrbHipError) as ei:             # the last pass held one pair only
+        orbhip.stereo_match_batch_device(gL, gR, n, kl.data_ptr(), dl.data_ptr(), cl.data_ptr(), kr.data_ptr(), dr.data_ptr(),
+                                         cr.data_ptr(), cap, BF / FX, BF, ur.data_ptr(), dp.data_ptr(), nm.data_ptr())
+    assert ei.value.code == orbhip.ERR_STATE

@@ -18,12 +18,21 @@
 #include <vector>
 
 #define ITERS 8192
-#define NOPS 55
-static const char* const kOpNames[NOPS] = {"v_mov_b32", "v_add_u32", "v_sub_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshrrev_b32 const", "v_lshrrev_b32 vgpr", "v_lshlrev_b32 const", "v_min_i32", "v_max_u32", "v_min_u16", "v_max_i16", "v_sub_u16", "v_add_u16", "v_cndmask_b32", "v_mul_u32_u24", "v_mul_lo_u32", "v_mad_u32_u24", "v_add_f32", "v_mul_f32", "v_fma_f32", "v_add_u32 dpp row_shr:1", "v_mov_b32 dpp row_shr:1", "v_mov_b32 dpp wave_shr:1", "v_add_u32 sdwa WORD_1", "v_sub_u16 sdwa hi", "v_pk_min_i16", "v_pk_max_i16", "v_pk_sub_i16", "v_pk_add_u16", "v_pk_lshrrev_b16", "v_perm_b32", "v_and_or_b32", "v_or3_b32", "v_add3_u32", "v_lshl_or_b32", "v_lshl_add_u32", "v_bfe_u32", "v_bfi_b32", "v_alignbit_b32", "v_alignbyte_b32", "v_min3_i32", "v_med3_i32", "v_sad_u8", "v_sad_u16", "v_msad_u8", "v_dot4_u32_u8", "v_dot2_u32_u16", "v_bcnt_u32_b32", "v_mbcnt_lo_u32_b32", "v_cmp_gt_i32 (vcc)", "v_cvt_f32_i32", "v_rndne_f32", "v_ffbl_b32"};
+#define NOPS 64
+static const char* const kOpNames[NOPS] = {"v_mov_b32", "v_add_u32", "v_sub_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshrrev_b32 const", "v_lshrrev_b32 vgpr", "v_lshlrev_b32 const", "v_min_i32", "v_max_u32", "v_min_u16", "v_max_i16", "v_sub_u16", "v_add_u16", "v_cndmask_b32", "v_mul_u32_u24", "v_mul_lo_u32", "v_mad_u32_u24", "v_add_f32", "v_mul_f32", "v_fma_f32", "v_add_u32 dpp row_shr:1", "v_mov_b32 dpp row_shr:1", "v_mov_b32 dpp wave_shr:1", "v_add_u32 sdwa WORD_1", "v_sub_u16 sdwa hi", "v_pk_min_i16", "v_pk_max_i16", "v_pk_sub_i16", "v_pk_add_u16", "v_pk_lshrrev_b16", "v_perm_b32", "v_and_or_b32", "v_or3_b32", "v_add3_u32", "v_lshl_or_b32", "v_lshl_add_u32", "v_bfe_u32", "v_bfi_b32", "v_alignbit_b32", "v_alignbyte_b32", "v_min3_i32", "v_med3_i32", "v_sad_u8", "v_sad_u16", "v_msad_u8", "v_dot4_u32_u8", "v_dot2_u32_u16", "v_bcnt_u32_b32", "v_mbcnt_lo_u32_b32", "v_cmp_gt_i32 (vcc)", "v_cvt_f32_i32", "v_rndne_f32", "v_ffbl_b32", "v_add_u32 (2 fresh srcs)", "v_sub_u32 (2 fresh srcs)", "v_or_b32 (2 fresh srcs)", "v_and_b32 (2 fresh srcs)", "v_add_u32 (src = sgpr)", "v_add_u32 (src = literal)", "v_lshrrev_b32 (fresh dst)", "v_mov_b32 (fresh)", "v_pk_min_i16 (2 fresh srcs)"};
 
 template <int OP>
-__device__ __forceinline__ void one(uint32_t& a, uint32_t b, uint32_t c) {
+__device__ __forceinline__ void one(uint32_t& a, uint32_t b, uint32_t c, uint32_t d, uint32_t sg) {
     if (OP < 0) {}
+    else if (OP == 55) asm volatile("v_add_u32 %0, %3, %1" : "+v"(a) : "v"(b), "v"(c), "v"(d), "s"(sg) : "vcc");
+    else if (OP == 56) asm volatile("v_sub_u32 %0, %3, %1" : "+v"(a) : "v"(b), "v"(c), "v"(d), "s"(sg) : "vcc");
+    else if (OP == 57) asm volatile("v_or_b32 %0, %3, %1" : "+v"(a) : "v"(b), "v"(c), "v"(d), "s"(sg) : "vcc");
+    else if (OP == 58) asm volatile("v_and_b32 %0, %3, %1" : "+v"(a) : "v"(b), "v"(c), "v"(d), "s"(sg) : "vcc");
+    else if (OP == 59) asm volatile("v_add_u32 %0, %4, %0" : "+v"(a) : "v"(b), "v"(c), "v"(d), "s"(sg) : "vcc");
+    else if (OP == 60) asm volatile("v_add_u32 %0, 0x12345, %0" : "+v"(a) : "v"(b), "v"(c), "v"(d), "s"(sg) : "vcc");
+    else if (OP == 61) asm volatile("v_lshrrev_b32 %0, 1, %3" : "+v"(a) : "v"(b), "v"(c), "v"(d), "s"(sg) : "vcc");
+    else if (OP == 62) asm volatile("v_mov_b32 %0, %3" : "+v"(a) : "v"(b), "v"(c), "v"(d), "s"(sg) : "vcc");
+    else if (OP == 63) asm volatile("v_pk_min_i16 %0, %3, %1" : "+v"(a) : "v"(b), "v"(c), "v"(d), "s"(sg) : "vcc");
     else if (OP == 0) asm volatile("v_mov_b32 %0, %1" : "+v"(a) : "v"(b), "v"(c) : "vcc");
     else if (OP == 1) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(b), "v"(c) : "vcc");
     else if (OP == 2) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a) : "v"(b), "v"(c) : "vcc");
@@ -92,7 +101,7 @@ __global__ __launch_bounds__(256) void k_calib(uint64_t* __restrict__ delta, uin
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) :: "memory");
     for (int i = 0; i < ITERS; i++) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) one<OP>(a[k], b, c);
+        for (int k = 0; k < 16; k++) one<OP>(a[k], a[(k + 5) & 15], c, a[(k + 9) & 15], seed);
     }
     asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
     uint32_t x = 0;
@@ -197,5 +206,14 @@ int main() {
     run<52>(ncu, d_delta, d_sink);
     run<53>(ncu, d_delta, d_sink);
     run<54>(ncu, d_delta, d_sink);
+    run<55>(ncu, d_delta, d_sink);
+    run<56>(ncu, d_delta, d_sink);
+    run<57>(ncu, d_delta, d_sink);
+    run<58>(ncu, d_delta, d_sink);
+    run<59>(ncu, d_delta, d_sink);
+    run<60>(ncu, d_delta, d_sink);
+    run<61>(ncu, d_delta, d_sink);
+    run<62>(ncu, d_delta, d_sink);
+    run<63>(ncu, d_delta, d_sink);
     return 0;
 }

@@ -78,6 +78,9 @@ struct PlanDev {
     // k_fast handles all levels in one launch: workgroups [fast_cum[l] * frames, fast_cum[l+1] * frames)
     // belong to level l (fast_cum = running sum of tiles per frame); magics for the divisions by the
     // tiles per frame and the tiles per row of a level (grid_magic)
+    // k_quadtree: slot of a level's node arrays in the global spill buffer, or -1 when they fit in LDS
+    int qt_spill_slot[ORB_MAX_LEVELS];
+    int qt_nspill;                       // levels with a slot
     uint32_t fast_cum[ORB_MAX_LEVELS + 1];
     uint32_t fast_tiles_magic[ORB_MAX_LEVELS], fast_ntx_magic[ORB_MAX_LEVELS];
     LevelGeom lv[ORB_MAX_LEVELS];

@@ -501,6 +501,12 @@ __device__ __forceinline__ void qt_for_keys(const uint2* keys, int nkeys, int ti
     }
 }
 
+// SPILL = false: the node arrays live in LDS (every level whose quota fits: 80 bytes per list node).
+// SPILL = true: the levels whose node arrays do not fit (quotas beyond ~2000 features on one level; the
+// reference has no such limit, src/ORBextractor.cc:539-763) keep them in a global scratch slice per
+// (frame, level) instead; the code is the same, the workgroup's barriers order its own global accesses
+// (all its waves share one CU and its cache). Each variant returns at once on the other's levels.
+template <bool SPILL>
 __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restrict__ plan,
                                                          const uint2* __restrict__ seg,
                                                          const int* __restrict__ seg_count,
@@ -508,8 +514,9 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
                                                          int* __restrict__ key_count,
                                                          LevelKp* __restrict__ lvl_kp,
                                                          int* __restrict__ lvl_cnt,
-                                                         int* __restrict__ status) {
-    extern __shared__ __align__(16) uint32_t smem[];
+                                                         int* __restrict__ status,
+                                                         uint32_t* __restrict__ spill, unsigned long long spill_stride) {
+    extern __shared__ __align__(16) uint32_t smem_lds[];
     __shared__ uint32_t s_tmp[QT_THREADS / 64];
     __shared__ uint32_t s_red[4];
     __shared__ int s_nkeys;
@@ -517,6 +524,9 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
     // Grid (frames, levels): consecutive workgroups, which are dealt to the 8 XCDs in turn, hold the
     // same level of different frames (the levels differ a lot in cost), the large levels first.
     const int f = blockIdx.x, level = blockIdx.y;
+    const int slot = plan->qt_spill_slot[level];
+    if ((slot >= 0) != SPILL) return;                          // uniform over the workgroup
+    uint32_t* const smem = SPILL ? spill + ((size_t)f * plan->qt_nspill + slot) * spill_stride : smem_lds;
     const LevelGeom g = plan->lv[level];
     const int M = g.node_cap;
     const int N = g.quota;

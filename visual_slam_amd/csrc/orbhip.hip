@@ -46,6 +46,7 @@ struct Workspace {
     int* d_key_count = nullptr;    // [frames][nlevels]
     LevelKp* d_lvl_kp = nullptr;   // [frames][kp_per_frame]
     int* d_lvl_cnt = nullptr;      // [frames][nlevels]
+    uint32_t* d_qt_spill = nullptr;   // [frames][levels that spill][qt_spill_words] node arrays of k_quadtree that do not fit in LDS
     hipStream_t stream = nullptr;  // used when two passes are in flight
     hipEvent_t done = nullptr;
 };
@@ -116,6 +117,7 @@ struct orbhip_extractor {
     float* d_map_y = nullptr;
     int map_w = 0, map_h = 0;
     size_t qt_lds = 0;
+    size_t qt_spill_words = 0;     // words of one (frame, level) slice of the quadtree's global spill buffer
     int last_pass_frames = 0;
     int last_ws = 0;               // workspace of the last pass (pyramid / candidate read-back)
     unsigned long long pass_gen = 0;       // counts passes: tags the host copy of a frame's pyramid
@@ -162,7 +164,7 @@ void free_plan(orbhip_extractor* e) {
     dfree(e->d_plan); dfree(e->d_tabs);
     for (Workspace& w : e->ws) {
         dfree(w.d_pyr); dfree(w.d_seg); dfree(w.d_seg_count);
-        dfree(w.d_keys); dfree(w.d_key_count); dfree(w.d_lvl_kp); dfree(w.d_lvl_cnt);
+        dfree(w.d_keys); dfree(w.d_key_count); dfree(w.d_lvl_kp); dfree(w.d_lvl_cnt); dfree(w.d_qt_spill);
     }
     e->plan_w = e->plan_h = e->plan_frames = e->plan_lanes = 0;
 }
@@ -256,7 +258,7 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
     }
     size_t pyr_off = 0, keys_off = 0, seg_off = 0;
     int segc_off = 0, kp_off = 0, tab_off = 0;
-    size_t max_qt_words = 0;
+    size_t max_qt_words = 0, spill_words = 0;
     for (int l = 0; l < nl; l++) {
         LevelGeom& g = P.lv[l];
         g.w = cv_round((float)w * e->inv_sf[l]);          // src/ORBextractor.cc:1111-1112
@@ -299,7 +301,17 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
         g.segc_off = segc_off; segc_off += g.ntx * g.nty * 4;
         g.keys_off = keys_off; keys_off += g.keys_cap;
         g.qt_words = std::max(20 * g.node_cap, g.ntx * g.nty * 4 + 1);
-        max_qt_words = std::max(max_qt_words, (size_t)g.qt_words + (size_t)(g.ncols * g.nrows + 31) / 32);
+        {
+            // node arrays (20 words per node) plus the per-cell bit mask: in LDS when they fit, else in a global slice
+            const size_t words = (size_t)g.qt_words + (size_t)(g.ncols * g.nrows + 31) / 32;
+            if (words * 4 > 160 * 1024 - 256) {
+                P.qt_spill_slot[l] = P.qt_nspill++;
+                spill_words = std::max(spill_words, (words + 63) / 64 * 64);
+            } else {
+                P.qt_spill_slot[l] = -1;
+                max_qt_words = std::max(max_qt_words, words);
+            }
+        }
         g.quota = e->per_level[l];
         g.kp_off = kp_off; kp_off += g.node_cap;
         g.scale = e->sf[l];
@@ -325,9 +337,8 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
     P.keys_per_frame = keys_off;
     P.kp_per_frame = kp_off;
     e->pyr_bytes_per_frame = pyr_off / frames;
-    // node arrays of k_quadtree (20 words per node) plus its per-cell bit mask
     e->qt_lds = max_qt_words * 4;
-    if (e->qt_lds > 160 * 1024 - 256) { e->err = "nfeatures per level too large for the on-chip quadtree"; return ORBHIP_ERR_ARG; }
+    e->qt_spill_words = spill_words;
     std::vector<RsTab> tabs((size_t)std::max(tab_off, 1));
     for (int l = 1; l < nl; l++) {
         const LevelGeom& g = P.lv[l];
@@ -359,6 +370,7 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
         HIP_TRY(e, hipMalloc(&W.d_key_count, (size_t)frames * nl * sizeof(int)));
         HIP_TRY(e, hipMalloc(&W.d_lvl_kp, (size_t)frames * P.kp_per_frame * sizeof(LevelKp)));
         HIP_TRY(e, hipMalloc(&W.d_lvl_cnt, (size_t)frames * nl * sizeof(int)));
+        if (P.qt_nspill) HIP_TRY(e, hipMalloc(&W.d_qt_spill, (size_t)frames * P.qt_nspill * spill_words * sizeof(uint32_t)));
         HIP_TRY(e, hipMemsetAsync(W.d_lvl_kp, 0, (size_t)frames * P.kp_per_frame * sizeof(LevelKp), e->stream));
     }
     HIP_TRY(e, hipMemcpyAsync(e->d_plan, &P, sizeof(PlanDev), hipMemcpyHostToDevice, e->stream));
@@ -366,7 +378,7 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     e->plan_lanes = lanes;
     if (e->qt_lds > 64 * 1024)
-        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->qt_lds));
+        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->qt_lds));
     e->plan_w = w; e->plan_h = h; e->plan_frames = frames;
     return ORBHIP_OK;
 }
@@ -461,9 +473,14 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
     if (split) HIP_TRY(e, hipStreamWaitEvent(s, e->ev_f0, 0));
     {
         SpanGuard t(e, s, KC_QUADTREE);
-        hipLaunchKernelGGL(k_quadtree, dim3(frames, nl), dim3(QT_THREADS), e->qt_lds, s,
-                           e->d_plan, W.d_seg, W.d_seg_count, W.d_keys, W.d_key_count, W.d_lvl_kp, W.d_lvl_cnt,
-                           e->d_status);
+        if (P.qt_nspill < nl)
+            hipLaunchKernelGGL(k_quadtree<false>, dim3(frames, nl), dim3(QT_THREADS), e->qt_lds, s,
+                               e->d_plan, W.d_seg, W.d_seg_count, W.d_keys, W.d_key_count, W.d_lvl_kp, W.d_lvl_cnt,
+                               e->d_status, static_cast<uint32_t*>(nullptr), 0ull);
+        if (P.qt_nspill)
+            hipLaunchKernelGGL(k_quadtree<true>, dim3(frames, nl), dim3(QT_THREADS), 0, s,
+                               e->d_plan, W.d_seg, W.d_seg_count, W.d_keys, W.d_key_count, W.d_lvl_kp, W.d_lvl_cnt,
+                               e->d_status, W.d_qt_spill, (unsigned long long)e->qt_spill_words);
     }
     {
         SpanGuard t(e, s, KC_DESCRIBE);
@@ -605,6 +622,18 @@ int orbhip_destroy(orbhip_extractor* e) {
     return ORBHIP_OK;
 }
 
+// Frames one pass may hold: max_batch, but keep the workspaces (about 20 bytes per input pixel and frame:
+// pyramid planes, FAST output segments, quadtree keys) under ~24 GB, and the descriptor kernel's
+// one-dimensional grid (8 * groups of 4 keypoints * frames / 8 workgroups) small enough for its 32-bit
+// multiply-high division, which is exact while grid * 8 * groups < 2^32.
+static int pass_budget(const orbhip_extractor* e, int width, int height) {
+    const double ws_per_frame = 20.0 * (double)width * (double)height;
+    const int ws_limit = std::max(1, (int)(24e9 / ws_per_frame));
+    const unsigned long long groups = ((unsigned long long)orbhip_max_keypoints(e) + 3) / 4;
+    const int grid_limit = (int)std::min<unsigned long long>(1u << 20, 8ull * (((1ull << 26) - 1) / (groups * groups)));
+    return std::max(1, std::min(std::min(e->prm.max_batch, ws_limit), std::max(grid_limit, 8)));
+}
+
 static int extract_device_impl(orbhip_extractor* e, const uint8_t* d_imgs, int nframes, int width, int height,
                                size_t row_stride, size_t frame_stride, int channels, int rgb, orbhip_keypoint* d_kp,
                                uint8_t* d_desc, int* d_counts, int cap, void* stream) {
@@ -623,15 +652,7 @@ static int extract_device_impl(orbhip_extractor* e, const uint8_t* d_imgs, int n
     // (ev_busy was recorded at the end of that call, so the earlier stream itself is not touched again)
     if (e->last_stream && e->last_stream != s) HIP_TRY(e, hipStreamWaitEvent(s, e->ev_busy, 0));
     e->last_stream = s;
-    // frames per pass: max_batch, but keep the workspaces (about 20 bytes per input pixel and frame:
-    // pyramid planes, FAST output segments, quadtree keys) under ~24 GB
-    const double ws_per_frame = 20.0 * (double)width * (double)height;
-    const int ws_limit = std::max(1, (int)(24e9 / ws_per_frame));
-    // the descriptor kernel's one-dimensional grid (8 * groups of 4 keypoints * frames / 8 workgroups) finds
-    // its frame with a 32-bit multiply-high division that is exact while grid * 8 * groups < 2^32
-    const unsigned long long groups = ((unsigned long long)orbhip_max_keypoints(e) + 3) / 4;
-    const int grid_limit = (int)std::min<unsigned long long>(1u << 20, 8ull * (((1ull << 26) - 1) / (groups * groups)));
-    const int budget = std::max(1, std::min(std::min(e->prm.max_batch, ws_limit), std::max(grid_limit, 8)));   // frames in flight
+    const int budget = pass_budget(e, width, height);          // frames in flight
     // Large batches run as passes of half the budget, alternating between two workspaces on two
     // internal streams that fork from and join back into the caller's stream. (Per-kernel timing
     // then measures every kernel as it runs, next to the other pass's kernels.)
@@ -989,16 +1010,8 @@ static int stereo_batch_launch(orbhip_extractor* left, orbhip_extractor* right, 
     return ORBHIP_OK;
 }
 
-int orbhip_stereo_match_batch_device(orbhip_extractor* left, orbhip_extractor* right, int nframes,
-                                     const orbhip_keypoint* d_kp_l, const uint8_t* d_desc_l, const int* d_cnt_l,
-                                     const orbhip_keypoint* d_kp_r, const uint8_t* d_desc_r, const int* d_cnt_r,
-                                     int cap, float mb, float mbf, float* d_uright, float* d_depth, int* d_nmatch,
-                                     void* stream) {
-    int rc = stereo_batch_check(left, right, nframes, d_kp_l, d_desc_l, d_cnt_l, d_kp_r, d_desc_r, d_cnt_r, cap, mb, d_uright, d_depth);
-    if (rc) return rc;
-    orbhip_extractor* e = left;
-    HIP_TRY(e, hipSetDevice(e->device));
-    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+// Scratch of the allocating entry points of the stereo matching, grown on demand (owned by the left instance).
+static int stereo_scratch(orbhip_extractor* e, int nframes, int cap) {
     const size_t need = (size_t)nframes * cap + (size_t)nframes;   // + a counter per frame when the caller wants none
     if (need > e->d_st_sad_n) {
         HIP_TRY(e, hipDeviceSynchronize());
@@ -1009,7 +1022,7 @@ int orbhip_stereo_match_batch_device(orbhip_extractor* left, orbhip_extractor* r
         e->d_st_sad_n = need;
     }
     int nbins, band;
-    stereo_bins(left, &nbins, &band);
+    stereo_bins(e, &nbins, &band);
     if ((size_t)nframes * (nbins + 1) > e->d_st_bins_n) {
         HIP_TRY(e, hipDeviceSynchronize());
         dfree(e->d_st_bins);
@@ -1017,6 +1030,21 @@ int orbhip_stereo_match_batch_device(orbhip_extractor* left, orbhip_extractor* r
         HIP_TRY(e, hipMalloc(&e->d_st_bins, (size_t)nframes * (nbins + 1) * sizeof(int)));
         e->d_st_bins_n = (size_t)nframes * (nbins + 1);
     }
+    return ORBHIP_OK;
+}
+
+int orbhip_stereo_match_batch_device(orbhip_extractor* left, orbhip_extractor* right, int nframes,
+                                     const orbhip_keypoint* d_kp_l, const uint8_t* d_desc_l, const int* d_cnt_l,
+                                     const orbhip_keypoint* d_kp_r, const uint8_t* d_desc_r, const int* d_cnt_r,
+                                     int cap, float mb, float mbf, float* d_uright, float* d_depth, int* d_nmatch,
+                                     void* stream) {
+    int rc = stereo_batch_check(left, right, nframes, d_kp_l, d_desc_l, d_cnt_l, d_kp_r, d_desc_r, d_cnt_r, cap, mb, d_uright, d_depth);
+    if (rc) return rc;
+    orbhip_extractor* e = left;
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    rc = stereo_scratch(left, nframes, cap);
+    if (rc) return rc;
     return stereo_batch_launch(left, right, nframes, d_kp_l, d_desc_l, d_cnt_l, d_kp_r, d_desc_r, d_cnt_r, cap, mb, mbf,
                                d_uright, d_depth, d_nmatch, s, e->d_st_sad, e->d_st_rinfo, e->d_st_bins, true);
 }
@@ -1046,6 +1074,73 @@ int orbhip_stereo_match_batch_device_noalloc(orbhip_extractor* left, orbhip_extr
     int* bins = reinterpret_cast<int*>(base + NOALLOC_RINFO_BYTES + NOALLOC_SAD_BYTES);
     return stereo_batch_launch(left, right, nframes, d_kp_l, d_desc_l, d_cnt_l, d_kp_r, d_desc_r, d_cnt_r, cap, mb, mbf,
                                d_uright, d_depth, d_nmatch, s, sad, rinfo, bins, false);
+}
+
+int orbhip_extract_stereo_batch_device(orbhip_extractor* left, orbhip_extractor* right,
+                                       const uint8_t* d_imgs_l, const uint8_t* d_imgs_r, int nframes, int width, int height,
+                                       size_t row_stride, size_t frame_stride,
+                                       orbhip_keypoint* d_kp_l, uint8_t* d_desc_l, int* d_cnt_l,
+                                       orbhip_keypoint* d_kp_r, uint8_t* d_desc_r, int* d_cnt_r, int cap,
+                                       float mb, float mbf, float* d_uright, float* d_depth, int* d_nmatch, void* stream) {
+    if (!left || !right || !d_kp_l || !d_desc_l || !d_cnt_l || !d_kp_r || !d_desc_r || !d_cnt_r || !d_uright || !d_depth ||
+        cap < 1 || cap > 65535 || nframes < 0 || !(mb > 0.f))
+        return ORBHIP_ERR_ARG;
+    if (!d_imgs_l || !d_imgs_r || width <= 0 || height <= 0 || nframes == 0) return ORBHIP_ERR_EMPTY;
+    if (row_stride < (size_t)width) return ORBHIP_ERR_ARG;
+    orbhip_extractor* e = left;
+    if (left->device != right->device || left->prm.nlevels != right->prm.nlevels || left->prm.scale_factor != right->prm.scale_factor) {
+        e->err = "left and right instances differ in device or pyramid parameters";
+        return ORBHIP_ERR_ARG;
+    }
+    orbhip_extractor* const sides[2] = {left, right};
+    for (orbhip_extractor* x : sides)
+        if (x->d_map_x && (width != x->map_w || height != x->map_h || width < 2 || height < 2)) {
+            e->err = "rectification maps are set: the input must be a gray image of the maps' size";
+            return ORBHIP_ERR_ARG;
+        }
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    for (orbhip_extractor* x : sides) {
+        if (x->last_stream && x->last_stream != s) HIP_TRY(e, hipStreamWaitEvent(s, x->ev_busy, 0));
+        x->last_stream = s;
+    }
+    // One pass of both instances at a time, matched before the next pass overwrites the pyramids: the
+    // matcher reads them where the extraction left them.
+    const int chunk = std::min(nframes, std::min(pass_budget(left, width, height), pass_budget(right, width, height)));
+    for (orbhip_extractor* x : sides)
+        if (x->plan_w != width || x->plan_h != height || x->plan_frames < chunk || x->plan_lanes < 1) {
+            HIP_TRY(e, hipDeviceSynchronize());
+            const bool same = x->plan_w == width && x->plan_h == height;
+            int rc = ensure_plan(x, width, height, std::max(chunk, same ? x->plan_frames : 0), std::max(1, same ? x->plan_lanes : 0));
+            if (rc) { if (x != e) e->err = x->err; return rc; }
+        }
+    if (left->plan_frames != right->plan_frames) {
+        // plane offsets depend on the frames a plan was made for: bring both instances to the same pass size
+        const int frames = std::max(left->plan_frames, right->plan_frames);
+        HIP_TRY(e, hipDeviceSynchronize());
+        for (orbhip_extractor* x : sides) {
+            int rc = ensure_plan(x, width, height, frames, std::max(1, x->plan_lanes));
+            if (rc) { if (x != e) e->err = x->err; return rc; }
+        }
+    }
+    int rc = stereo_scratch(left, chunk, cap);
+    if (rc) return rc;
+    for (int f0 = 0; f0 < nframes; f0 += chunk) {
+        const int n = std::min(chunk, nframes - f0);
+        rc = run_pass(left, left->ws[0], s, d_imgs_l + (size_t)f0 * frame_stride, n, row_stride, frame_stride, 1, 0,
+                      reinterpret_cast<float*>(d_kp_l), d_desc_l, d_cnt_l, cap, f0);
+        if (rc) return rc;
+        rc = run_pass(right, right->ws[0], s, d_imgs_r + (size_t)f0 * frame_stride, n, row_stride, frame_stride, 1, 0,
+                      reinterpret_cast<float*>(d_kp_r), d_desc_r, d_cnt_r, cap, f0);
+        if (rc) { e->err = right->err; return rc; }
+        const size_t o = (size_t)f0 * cap;
+        rc = stereo_batch_launch(left, right, n, d_kp_l + o, d_desc_l + o * 32, d_cnt_l + f0, d_kp_r + o, d_desc_r + o * 32, d_cnt_r + f0,
+                                 cap, mb, mbf, d_uright + o, d_depth + o, d_nmatch ? d_nmatch + f0 : nullptr, s,
+                                 e->d_st_sad, e->d_st_rinfo, e->d_st_bins, true);
+        if (rc) return rc;
+    }
+    for (orbhip_extractor* x : sides) HIP_TRY(e, hipEventRecord(x->ev_busy, s));
+    return ORBHIP_OK;
 }
 
 int orbhip_stereo_match(orbhip_extractor* left, orbhip_extractor* right,

@@ -31,7 +31,7 @@ EXPORTS = [
     "orbhip_get_features_per_level", "orbhip_get_umax", "orbhip_pyramid_info", "orbhip_pyramid_copy",
     "orbhip_debug_candidates", "orbhip_enable_timing", "orbhip_get_timing", "orbhip_strerror",
     "orbhip_last_error", "orbhip_stereo_match", "orbhip_stereo_match_batch_device",
-    "orbhip_stereo_match_batch_device_noalloc",
+    "orbhip_stereo_match_batch_device_noalloc", "orbhip_extract_stereo_batch_device",
     "orbhip_extract_color", "orbhip_extract_batch_device_color",
     "orbhip_image_bounds", "orbhip_undistort_grid", "orbhip_undistort_grid_batch_device",
     "orbhip_search_for_initialization", "orbhip_search_for_initialization_batch_device",
@@ -133,6 +133,8 @@ def lib():
         L.orbhip_stereo_match_batch_device.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float,
                                                        vp, vp, vp, vp]
         L.orbhip_stereo_match_batch_device_noalloc.argtypes = L.orbhip_stereo_match_batch_device.argtypes
+        L.orbhip_extract_stereo_batch_device.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
+                                                         vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -394,6 +396,15 @@ def stereo_match_batch_device(left, right, nframes, d_kp_l, d_desc_l, d_cnt_l, d
     fn = lib().orbhip_stereo_match_batch_device_noalloc if noalloc else lib().orbhip_stereo_match_batch_device
     left._check(fn(left._h, right._h, nframes, d_kp_l, d_desc_l, d_cnt_l, d_kp_r, d_desc_r, d_cnt_r, cap, mb, mbf,
                    d_uright, d_depth, d_nmatch, stream))
+
+
+def extract_stereo_batch_device(left, right, d_imgs_l, d_imgs_r, nframes, w, h, row_stride, frame_stride,
+                                d_kp_l, d_desc_l, d_cnt_l, d_kp_r, d_desc_r, d_cnt_r, cap, mb, mbf,
+                                d_uright, d_depth, d_nmatch=None, stream=None):
+    """Both extractions and the stereo matching of a device-resident batch of pairs of any size (raw pointers)."""
+    left._check(lib().orbhip_extract_stereo_batch_device(left._h, right._h, d_imgs_l, d_imgs_r, nframes, w, h, row_stride, frame_stride,
+                                                         d_kp_l, d_desc_l, d_cnt_l, d_kp_r, d_desc_r, d_cnt_r, cap, mb, mbf,
+                                                         d_uright, d_depth, d_nmatch, stream))
 
 
 class ORBextractor:
