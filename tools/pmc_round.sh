@@ -15,12 +15,20 @@ run() {   # name, counters, program...: the per-kernel sums go to $out/name.txt,
     local db=$(find $out -name "${name}_results.db" | head -1)
     python3 tools/pmc_summary.py "$db" > $out/$name.txt 2>&1 && rm -f "$db" && tail -4 $out/$name.log > $out/$name.log.tail && rm -f $out/$name.log
 }
-B="python3 bench.py --steps 2 --warmup 1 --cpu-frames 0"
-run ext_lds "$LDS" $B && run ext_issue "$ISSUE" $B && run ext_fetch FETCH_SIZE $B && run ext_write WRITE_SIZE $B && run ext_clk GRBM_GUI_ACTIVE $B || exit 1
+trace() {   # name, program...: kernel durations (rocprofv3 --kernel-trace --stats) as text
+    local name=$1; shift
+    timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d $out -o $name -- "$@" > $out/$name.log 2>&1 || { echo "trace $name failed"; tail -15 $out/$name.log; return 1; }
+    local db=$(find $out -name "${name}_results.db" | head -1)
+    python3 tools/prof_summary.py "$db" > $out/$name.txt 2>&1 && rm -f "$db" $out/$name.log
+    find $out -name "${name}_*.csv" -delete
+}
+B="python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --batch 512"
+trace ext_trace python3 bench.py --cpu-frames 0 --batch 512 && run ext_lds "$LDS" $B && run ext_issue "$ISSUE" $B && run ext_fetch FETCH_SIZE $B && run ext_write WRITE_SIZE $B && run ext_clk GRBM_GUI_ACTIVE $B || exit 1
 if [ "$2" != "ext" ]; then
-    S="python3 bench.py --stereo --workload C2_kitti --steps 2 --warmup 1 --cpu-frames 0"
-    run st_lds "$LDS" $S && run st_issue "$ISSUE" $S && run st_fetch FETCH_SIZE $S && run st_write WRITE_SIZE $S || exit 1
+    S="python3 bench.py --stereo --workload C2_kitti --steps 2 --warmup 1 --cpu-frames 0 --batch 256"
+    trace st_trace $S && run st_lds "$LDS" $S && run st_issue "$ISSUE" $S && run st_fetch FETCH_SIZE $S && run st_write WRITE_SIZE $S && run st_clk GRBM_GUI_ACTIVE $S || exit 1
     M="python3 tools/match_bench.py --steps 2 --cpu-pairs 0"
-    run m_lds "$LDS" $M && run m_issue "$ISSUE" $M && run m_fetch FETCH_SIZE $M && run m_write WRITE_SIZE $M || exit 1
+    trace m_trace $M && run m_lds "$LDS" $M && run m_issue "$ISSUE" $M && run m_fetch FETCH_SIZE $M && run m_write WRITE_SIZE $M && run m_clk GRBM_GUI_ACTIVE $M || exit 1
 fi
-ls $out | head -50
+for p in ext st m; do [ -f $out/${p}_lds.txt ] && python3 tools/pmc_report.py $out $p > $out/${p}_report.json; done
+ls $out | head -60
