@@ -425,8 +425,9 @@ int orbhip_search_by_bow_keyframes(orbhip_extractor* e, const orbhip_keypoint* k
  * during the call); mvScaleFactors are the handle's; nnratio is the matcher's mfNNratio.
  * Output: d_match[f][idx] = index of the map point the reference assigns to F.mvpMapPoints[idx]
  * (the last one, if several), -1 where it assigns none; d_nmatches[f] = the returned count.
- * Asynchronous on `stream` (NULL: the handle's). One workgroup per frame; 17 bytes of on-chip state
- * per map point slot and 17 per keypoint slot must fit 140 KB, else ORBHIP_ERR_CAPACITY. */
+ * Asynchronous on `stream` (NULL: the handle's). One workgroup per frame; its state (17 bytes per map
+ * point slot and 17 per keypoint slot) lives on chip while it fits 140 KB and in a global-memory slice
+ * beyond that (slower, same results). */
 typedef struct orbhip_track_point {
     float proj_x, proj_y, proj_xr, view_cos;
     int32_t level, flags;

@@ -275,3 +275,21 @@ def test_hip_sim3_projection_matches_oracle(cam, w, h, dx, dy, th, scale):
         gm, gn = orbhip.SearchByProjectionSim3(ex, s["world"], s["normal"], s["range"], s["flags"], s["d1"], s["u2"], s["d2"], None,
                                                s["Scw"], s["cam4"], s["bounds"], th)
         assert gn == on and np.array_equal(gm, om)
+
+
+@pytest.mark.gpu
+def test_hip_search_by_projection_large_frames_in_global_memory():
+    """8000 features per frame (the deep-pyramid configuration): far more keypoints than the matcher's on-chip state
+    holds (~2800), so the kernels keep their state in global memory; results still equal the oracle's, for the
+    motion-model, the key-frame and (with fewer points) every mode's code path."""
+    from visual_slam_amd import orbhip
+    prm = (8000, 1.2, 8, 20, 7)
+    s = scenario(1920, 1080, 75, 7, -4, KITTI, stereo=True, prm=prm)
+    assert len(s["u1"]) > 6000 and len(s["u2"]) > 6000
+    ex = orbhip.ORBextractor(*prm)
+    for th, mode in ((7, 0), (15, 1)):
+        om, on = run_oracle(s, th, mode, True)
+        gm, gn = orbhip.SearchByProjection(ex, s["u1"], s["world"], s["flags"], s["d1"], s["u2"], s["d2"], s["uright"], s["Tcw"],
+                                           s["cam4"], s["mbf"], s["bounds"], th, mode, True)
+        assert on > 1000 and gn == on
+        assert np.array_equal(gm, om)

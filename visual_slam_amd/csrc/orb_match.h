@@ -256,16 +256,21 @@ struct KeyframeArgs {
     int nlevels;
 };
 
-template <int MODE>
+// SPILL: frames with more keypoints than the workgroup's LDS can describe (beyond ~2800 per frame) keep the same state in
+// a slice of global memory (`spill + frame * spill_stride`); the code is the same, slower, and the workgroup's barriers
+// order its own global accesses.
+template <int MODE, bool SPILL = false>
 __global__ __launch_bounds__(MP_THREADS) void k_search_proj(const GridKp* __restrict__ kp1, const float* __restrict__ world1,
                                                      const uint8_t* __restrict__ flags1, const uint8_t* __restrict__ desc1,
                                                      const int* __restrict__ cnt1, const GridKp* __restrict__ kp2,
                                                      const uint8_t* __restrict__ desc2, const float* __restrict__ uright2,
                                                      const int* __restrict__ cnt2, int cap, const float* __restrict__ Tcw,
                                                      const int* __restrict__ level_mode, ProjArgs a, ScaleTab sf, KeyframeArgs kf,
-                                                     int* __restrict__ match2, int* __restrict__ nmatches_out) {
+                                                     int* __restrict__ match2, int* __restrict__ nmatches_out,
+                                                     uint8_t* __restrict__ spill = nullptr, size_t spill_stride = 0) {
     constexpr bool KEYFRAME = MODE != 0, SIM3 = MODE == 2;
-    extern __shared__ __align__(16) uint8_t mp_smem[];
+    extern __shared__ __align__(16) uint8_t mp_lds[];
+    uint8_t* const mp_smem = SPILL ? spill + (size_t)blockIdx.x * spill_stride : mp_lds;
     uint32_t* list1 = reinterpret_cast<uint32_t*>(mp_smem);                  // last: MP_LIST x (distance << 16 | current index), best first, occupancy ignored
     float2* pos2 = reinterpret_cast<float2*>(list1 + MP_LIST * (size_t)cap);  // current keypoints: position
     float2* uv1 = pos2 + cap;                                                // last keypoints: projection (u, v)
@@ -783,14 +788,17 @@ struct TrackPt { float x, y, xr, view_cos; int level, flags; };   // flags: 1 = 
 #define ML_LDS_PER_MP 17      // dynamic LDS bytes per map point slot
 #define ML_LDS_PER_KP 17      // and per keypoint slot
 
+template <bool SPILL = false>
 __global__ __launch_bounds__(MP_THREADS) void k_search_map(const TrackPt* __restrict__ mp, const uint8_t* __restrict__ desc1,
                                                            const int* __restrict__ cnt1, int cap1,
                                                            const GridKp* __restrict__ kp2, const uint8_t* __restrict__ desc2,
                                                            const float* __restrict__ uright2, const uint8_t* __restrict__ occupied2,
                                                            const int* __restrict__ cnt2, int cap2, float min_x, float min_y,
                                                            float inv_w, float inv_h, float th, float nnratio, ScaleTab sf, int nlevels,
-                                                           int* __restrict__ match2, int* __restrict__ nmatches_out) {
-    extern __shared__ __align__(16) uint8_t ml_smem[];
+                                                           int* __restrict__ match2, int* __restrict__ nmatches_out,
+                                                           uint8_t* __restrict__ spill = nullptr, size_t spill_stride = 0) {
+    extern __shared__ __align__(16) uint8_t ml_lds[];
+    uint8_t* const ml_smem = SPILL ? spill + (size_t)blockIdx.x * spill_stride : ml_lds;   // as in k_search_proj
     uint32_t* list1 = reinterpret_cast<uint32_t*>(ml_smem);                  // map point: MP_LIST x (distance << 16 | keypoint), best first
     float2* pos2 = reinterpret_cast<float2*>(list1 + MP_LIST * (size_t)cap1);  // keypoint: position
     float* ur2 = reinterpret_cast<float*>(pos2 + cap2);                      // mvuRight

@@ -136,6 +136,7 @@ struct orbhip_extractor {
     int4* d_st_rinfo = nullptr;                          // [frames][cap] row band / octave / x of the right keypoints, binned by row
     int* d_st_bins = nullptr; size_t d_st_bins_n = 0;    // [frames][nbins + 1] record range of every row bin
     uint8_t* d_st_tmp = nullptr; size_t d_st_tmp_bytes = 0;   // staging of the host-array entry point
+    uint8_t* d_match_spill = nullptr; size_t d_match_spill_bytes = 0;   // matcher state of frames too large for LDS
     // timing
     bool timing = false;
     std::vector<TimedSpan> spans;
@@ -602,7 +603,7 @@ int orbhip_destroy(orbhip_extractor* e) {
     for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
     free_plan(e);
     dfree(e->d_status); dfree(e->d_in); dfree(e->d_out_kp); dfree(e->d_out_desc); dfree(e->d_out_cnt);
-    dfree(e->d_st_sad); dfree(e->d_st_rinfo); dfree(e->d_st_bins); dfree(e->d_st_tmp);
+    dfree(e->d_st_sad); dfree(e->d_st_rinfo); dfree(e->d_st_bins); dfree(e->d_st_tmp); dfree(e->d_match_spill);
     dfree(e->d_map_x); dfree(e->d_map_y);
     if (e->h_in) (void)hipHostFree(e->h_in);
     if (e->h_out) (void)hipHostFree(e->h_out);
@@ -1415,6 +1416,18 @@ int orbhip_projection_level_mode(const float* Tcw_cur, const float* Tcw_last, fl
     return 0;
 }
 
+// Global-memory state of the matchers for frames whose state does not fit a workgroup's LDS: `bytes` per frame.
+static int match_spill(orbhip_extractor* e, size_t bytes) {
+    if (bytes > e->d_match_spill_bytes) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        dfree(e->d_match_spill);
+        e->d_match_spill_bytes = 0;
+        HIP_TRY(e, hipMalloc(&e->d_match_spill, bytes));
+        e->d_match_spill_bytes = bytes;
+    }
+    return ORBHIP_OK;
+}
+
 int orbhip_search_by_projection_batch_device(orbhip_extractor* e, int nframes, int cap,
                                              const orbhip_keypoint* d_kp_last, const float* d_world_last,
                                              const uint8_t* d_flags_last, const uint8_t* d_desc_last, const int* d_cnt_last,
@@ -1427,10 +1440,10 @@ int orbhip_search_by_projection_batch_device(orbhip_extractor* e, int nframes, i
         !(prm->bounds[1] > prm->bounds[0]) || !(prm->bounds[3] > prm->bounds[2]))
         return ORBHIP_ERR_ARG;
     const size_t lds = (size_t)MP_LDS_PER_KP * cap + 16;
-    if (lds > 160 * 1024 - 20 * 1024) { e->err = "too many keypoints per frame for the on-chip matcher state"; return ORBHIP_ERR_CAPACITY; }
+    const bool spill = lds > 160 * 1024 - 20 * 1024;                // the state then lives in global memory
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
-    if (lds > 40 * 1024)
+    if (!spill && lds > 40 * 1024)
         HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_proj<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProjArgs a;
     a.fx = prm->fx; a.fy = prm->fy; a.cx = prm->cx; a.cy = prm->cy; a.mbf = prm->mbf;
@@ -1441,9 +1454,18 @@ int orbhip_search_by_projection_batch_device(orbhip_extractor* e, int nframes, i
     a.check_orientation = prm->check_orientation;
     ScaleTab sf;
     for (int l = 0; l < ORB_MAX_LEVELS; l++) sf.v[l] = e->sf[std::min(l, e->prm.nlevels - 1)];
-    hipLaunchKernelGGL(k_search_proj<0>, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const GridKp*>(d_kp_last), d_world_last,
-                       d_flags_last, d_desc_last, d_cnt_last, reinterpret_cast<const GridKp*>(d_kp_cur), d_desc_cur, d_uright_cur,
-                       d_cnt_cur, cap, d_Tcw, d_level_mode, a, sf, KeyframeArgs{nullptr, nullptr, nullptr, 0, 0.0f, 0}, d_match_cur, d_nmatches);
+    if (spill) {
+        const size_t stride = (lds + 255) & ~(size_t)255;
+        int rc = match_spill(e, stride * (size_t)nframes);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_search_proj<0, true>), dim3(nframes), dim3(MP_THREADS), 0, s, reinterpret_cast<const GridKp*>(d_kp_last), d_world_last,
+                           d_flags_last, d_desc_last, d_cnt_last, reinterpret_cast<const GridKp*>(d_kp_cur), d_desc_cur, d_uright_cur,
+                           d_cnt_cur, cap, d_Tcw, d_level_mode, a, sf, KeyframeArgs{nullptr, nullptr, nullptr, 0, 0.0f, 0}, d_match_cur, d_nmatches, e->d_match_spill, stride);
+    } else {
+        hipLaunchKernelGGL(k_search_proj<0>, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const GridKp*>(d_kp_last), d_world_last,
+                           d_flags_last, d_desc_last, d_cnt_last, reinterpret_cast<const GridKp*>(d_kp_cur), d_desc_cur, d_uright_cur,
+                           d_cnt_cur, cap, d_Tcw, d_level_mode, a, sf, KeyframeArgs{nullptr, nullptr, nullptr, 0, 0.0f, 0}, d_match_cur, d_nmatches);
+    }
     HIP_TRY(e, hipGetLastError());
     return ORBHIP_OK;
 }
@@ -1514,10 +1536,10 @@ int orbhip_search_by_projection_keyframe_batch_device(orbhip_extractor* e, int n
         !(prm->bounds[1] > prm->bounds[0]) || !(prm->bounds[3] > prm->bounds[2]))
         return ORBHIP_ERR_ARG;
     const size_t lds = (size_t)MP_LDS_PER_KP * cap + 16;
-    if (lds > 160 * 1024 - 20 * 1024) { e->err = "too many keypoints per frame for the on-chip matcher state"; return ORBHIP_ERR_CAPACITY; }
+    const bool spill = lds > 160 * 1024 - 20 * 1024;                // the state then lives in global memory
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
-    if (lds > 40 * 1024)
+    if (!spill && lds > 40 * 1024)
         HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_proj<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProjArgs a;
     a.fx = prm->fx; a.fy = prm->fy; a.cx = prm->cx; a.cy = prm->cy; a.mbf = prm->mbf;
@@ -1530,9 +1552,18 @@ int orbhip_search_by_projection_keyframe_batch_device(orbhip_extractor* e, int n
     for (int l = 0; l < ORB_MAX_LEVELS; l++) sf.v[l] = e->sf[std::min(l, e->prm.nlevels - 1)];
     const KeyframeArgs kf{reinterpret_cast<const float2*>(d_dist_range_kf), d_occupied_cur, nullptr, orb_dist,
                           std::log((float)e->scale_factor_d), e->prm.nlevels};
-    hipLaunchKernelGGL(k_search_proj<1>, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const GridKp*>(d_kp_kf), d_world_kf,
-                       d_flags_kf, d_desc_kf, d_cnt_kf, reinterpret_cast<const GridKp*>(d_kp_cur), d_desc_cur, (const float*)nullptr,
-                       d_cnt_cur, cap, d_Tcw, (const int*)nullptr, a, sf, kf, d_match_cur, d_nmatches);
+    if (spill) {
+        const size_t stride = (lds + 255) & ~(size_t)255;
+        int rc = match_spill(e, stride * (size_t)nframes);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_search_proj<1, true>), dim3(nframes), dim3(MP_THREADS), 0, s, reinterpret_cast<const GridKp*>(d_kp_kf), d_world_kf,
+                           d_flags_kf, d_desc_kf, d_cnt_kf, reinterpret_cast<const GridKp*>(d_kp_cur), d_desc_cur, (const float*)nullptr,
+                           d_cnt_cur, cap, d_Tcw, (const int*)nullptr, a, sf, kf, d_match_cur, d_nmatches, e->d_match_spill, stride);
+    } else {
+        hipLaunchKernelGGL(k_search_proj<1>, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const GridKp*>(d_kp_kf), d_world_kf,
+                           d_flags_kf, d_desc_kf, d_cnt_kf, reinterpret_cast<const GridKp*>(d_kp_cur), d_desc_cur, (const float*)nullptr,
+                           d_cnt_cur, cap, d_Tcw, (const int*)nullptr, a, sf, kf, d_match_cur, d_nmatches);
+    }
     HIP_TRY(e, hipGetLastError());
     return ORBHIP_OK;
 }
@@ -1559,10 +1590,10 @@ int orbhip_search_by_projection_sim3_batch_device(orbhip_extractor* e, int nfram
         !(prm->bounds[1] > prm->bounds[0]) || !(prm->bounds[3] > prm->bounds[2]))
         return ORBHIP_ERR_ARG;
     const size_t lds = (size_t)MP_LDS_PER_KP * cap + 16;
-    if (lds > 160 * 1024 - 20 * 1024) { e->err = "too many keypoints or map points per frame for the on-chip matcher state"; return ORBHIP_ERR_CAPACITY; }
+    const bool spill = lds > 160 * 1024 - 20 * 1024;                // the state then lives in global memory
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
-    if (lds > 40 * 1024)
+    if (!spill && lds > 40 * 1024)
         HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_proj<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProjArgs a;
     a.fx = prm->fx; a.fy = prm->fy; a.cx = prm->cx; a.cy = prm->cy; a.mbf = prm->mbf;
@@ -1575,9 +1606,18 @@ int orbhip_search_by_projection_sim3_batch_device(orbhip_extractor* e, int nfram
     for (int l = 0; l < ORB_MAX_LEVELS; l++) sf.v[l] = e->sf[std::min(l, e->prm.nlevels - 1)];
     const KeyframeArgs kf{reinterpret_cast<const float2*>(d_dist_range), d_occupied_kf, d_normal, MT_TH_LOW,
                           std::log((float)e->scale_factor_d), e->prm.nlevels};
-    hipLaunchKernelGGL(k_search_proj<2>, dim3(nframes), dim3(MP_THREADS), lds, s, (const GridKp*)nullptr, d_world, d_flags, d_desc,
-                       d_cnt_pts, reinterpret_cast<const GridKp*>(d_kp_kf), d_desc_kf, (const float*)nullptr, d_cnt_kf, cap, d_Tcw,
-                       (const int*)nullptr, a, sf, kf, d_match_kf, d_nmatches);
+    if (spill) {
+        const size_t stride = (lds + 255) & ~(size_t)255;
+        int rc = match_spill(e, stride * (size_t)nframes);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_search_proj<2, true>), dim3(nframes), dim3(MP_THREADS), 0, s, (const GridKp*)nullptr, d_world, d_flags, d_desc,
+                           d_cnt_pts, reinterpret_cast<const GridKp*>(d_kp_kf), d_desc_kf, (const float*)nullptr, d_cnt_kf, cap, d_Tcw,
+                           (const int*)nullptr, a, sf, kf, d_match_kf, d_nmatches, e->d_match_spill, stride);
+    } else {
+        hipLaunchKernelGGL(k_search_proj<2>, dim3(nframes), dim3(MP_THREADS), lds, s, (const GridKp*)nullptr, d_world, d_flags, d_desc,
+                           d_cnt_pts, reinterpret_cast<const GridKp*>(d_kp_kf), d_desc_kf, (const float*)nullptr, d_cnt_kf, cap, d_Tcw,
+                           (const int*)nullptr, a, sf, kf, d_match_kf, d_nmatches);
+    }
     HIP_TRY(e, hipGetLastError());
     return ORBHIP_OK;
 }
@@ -1817,19 +1857,28 @@ int orbhip_search_map_points_batch_device(orbhip_extractor* e, int nframes, int 
         return ORBHIP_ERR_ARG;
     static_assert(sizeof(orbhip_track_point) == sizeof(TrackPt), "track point layout");
     const size_t lds = (size_t)ML_LDS_PER_MP * cap_mp + (size_t)ML_LDS_PER_KP * cap_kp + 32;
-    if (lds > 160 * 1024 - 20 * 1024) { e->err = "too many map points and keypoints per frame for the on-chip matcher state"; return ORBHIP_ERR_CAPACITY; }
+    const bool spill = lds > 160 * 1024 - 20 * 1024;                // the state then lives in global memory
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
-    if (lds > 40 * 1024)
-        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_map), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (!spill && lds > 40 * 1024)
+        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_map<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ScaleTab sf;
     for (int l = 0; l < ORB_MAX_LEVELS; l++) sf.v[l] = e->sf[std::min(l, e->prm.nlevels - 1)];
     const float inv_w = static_cast<float>(GRID_COLS) / (bounds[1] - bounds[0]);   // src/Frame.cc:128-129
     const float inv_h = static_cast<float>(GRID_ROWS) / (bounds[3] - bounds[2]);
     // the map point lists come first in the carve-up and are written 16 bytes at a time: 16 * cap_mp keeps every later array aligned
-    hipLaunchKernelGGL(k_search_map, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const TrackPt*>(d_mp), d_desc_mp, d_cnt_mp,
-                       cap_mp, reinterpret_cast<const GridKp*>(d_kp), d_desc, d_uright, d_occupied, d_cnt_kp, cap_kp, bounds[0], bounds[2],
-                       inv_w, inv_h, th, nnratio, sf, e->prm.nlevels, d_match, d_nmatches);
+    if (spill) {
+        const size_t stride = (lds + 255) & ~(size_t)255;
+        int rc = match_spill(e, stride * (size_t)nframes);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_search_map<true>, dim3(nframes), dim3(MP_THREADS), 0, s, reinterpret_cast<const TrackPt*>(d_mp), d_desc_mp, d_cnt_mp,
+                           cap_mp, reinterpret_cast<const GridKp*>(d_kp), d_desc, d_uright, d_occupied, d_cnt_kp, cap_kp, bounds[0], bounds[2],
+                           inv_w, inv_h, th, nnratio, sf, e->prm.nlevels, d_match, d_nmatches, e->d_match_spill, stride);
+    } else {
+        hipLaunchKernelGGL(k_search_map<false>, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const TrackPt*>(d_mp), d_desc_mp, d_cnt_mp,
+                           cap_mp, reinterpret_cast<const GridKp*>(d_kp), d_desc, d_uright, d_occupied, d_cnt_kp, cap_kp, bounds[0], bounds[2],
+                           inv_w, inv_h, th, nnratio, sf, e->prm.nlevels, d_match, d_nmatches);
+    }
     HIP_TRY(e, hipGetLastError());
     return ORBHIP_OK;
 }
