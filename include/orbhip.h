@@ -77,7 +77,14 @@ int orbhip_extract(orbhip_extractor* e, const uint8_t* img, int width, int heigh
  * buffers: d_kp[nframes][cap], d_desc[nframes][cap][32], d_counts[nframes]. Work is enqueued on
  * `stream` (a hipStream_t, NULL = the handle's own stream) and the call returns without waiting;
  * frames beyond max_batch are processed in consecutive passes. This is the entry point the
- * multi-GPU batch driver shards over (one handle per device, no collective). */
+ * multi-GPU batch driver shards over (one handle per device, no collective).
+ * Level 0 in place: the reference copies the image into a bordered level-0 buffer
+ * (src/ORBextractor.cc:1113-1128); when d_imgs, row_stride and frame_stride are multiples of 4 and
+ * width is too, the image itself serves as level 0 and the copy is skipped (same results; the
+ * environment variable ORBHIP_INPLACE_LEVEL0=0, read by orbhip_create, forces the copy). The images
+ * must then stay unchanged not only until the enqueued work has run, as for any asynchronous call, but
+ * for as long as level 0 of this pass is used: a later orbhip_stereo_match_batch_device* on this handle
+ * and orbhip_pyramid_copy read it from d_imgs. */
 int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int nframes, int width,
                                 int height, size_t row_stride, size_t frame_stride,
                                 orbhip_keypoint* d_kp, uint8_t* d_desc, int* d_counts, int cap,

@@ -1,0 +1,132 @@
+"""Level 0 read in place from the caller's image against level 0 copied into its bordered plane.
+
+A gray input whose rows can be read as aligned dwords is used as level 0 where it lies (FAST, the resize to
+level 1, the descriptors and the stereo refinement read the caller's buffer); any other input is copied into a
+plane first, as src/ORBextractor.cc:1113-1128 does. Both routes must give the same bits: these tests run the two
+(ORBHIP_INPLACE_LEVEL0=0 selects the copy when the handle is created) on device-resident batches of several
+shapes and strides, compare each with the other and with the oracle, and check the places where the in-place
+route differs in code: keypoints whose blurred patch leaves the image, the last bytes of a row in the resize
+to level 1, the bordered level-0 image asked for after the fact, and the stereo refinement.
+
+The oracle is pinned by analytic known answers only (the reference holds no vectors): parity unpinned.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.parity import DESC_MIN_EXACT, compare_outputs
+from visual_slam_amd import synth
+
+PRM = (1000, 1.2, 8, 20, 7)
+
+
+def _extractor(inplace, prm=PRM):
+    from visual_slam_amd import orbhip
+    old = os.environ.get("ORBHIP_INPLACE_LEVEL0")
+    os.environ["ORBHIP_INPLACE_LEVEL0"] = "1" if inplace else "0"
+    try:
+        return orbhip.ORBextractor(*prm)
+    finally:
+        if old is None:
+            del os.environ["ORBHIP_INPLACE_LEVEL0"]
+        else:
+            os.environ["ORBHIP_INPLACE_LEVEL0"] = old
+
+
+def _run_device(g, frames, pad=0, offset=0):
+    """Extraction of a device-resident batch; rows `pad` bytes longer than the image, the batch `offset` bytes into its buffer."""
+    import torch
+    n, h, w = frames.shape
+    dev = torch.device("cuda:0")
+    rs = w + pad
+    buf = torch.zeros(offset + n * h * rs, dtype=torch.uint8, device=dev)
+    view = buf[offset:].view(n, h, rs)
+    view[:, :, :w] = torch.from_numpy(frames).to(dev)
+    if pad:
+        view[:, :, w:] = 0xA5                                      # must never reach a result
+    cap = g.max_keypoints()
+    kp = torch.zeros((n, cap, 7), dtype=torch.float32, device=dev)
+    desc = torch.zeros((n, cap, 32), dtype=torch.uint8, device=dev)
+    cnt = torch.zeros((n,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    g.extract_batch_device(buf.data_ptr() + offset, n, w, h, rs, h * rs, kp.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap)
+    g.synchronize()
+    torch.cuda.synchronize()
+    c = cnt.cpu().numpy()
+    return [(kp[i, :c[i]].cpu().numpy().copy(), desc[i, :c[i]].cpu().numpy().copy()) for i in range(n)], buf
+
+
+SHAPES = [
+    # (w, h, pad, offset, kind): multiples of 4 read in place; the others (and odd strides / offsets) are copied on both handles
+    (640, 480, 0, 0, "blocks"),
+    (640, 480, 0, 0, "noise"),          # keypoints all along the edge of the detectable area: the reflecting patch path
+    (752, 480, 0, 0, "lowc"),
+    (324, 200, 0, 0, "noise"),          # one block column in the resize to level 1: every lane in the clamping variant
+    (1920, 1080, 0, 0, "blocks"),
+    (644, 360, 12, 0, "noise"),         # padded rows (aligned): in place, and the padding must not be read into a result
+    (644, 360, 12, 8, "blocks"),        # batch starts 8 bytes into its allocation
+    (641, 479, 0, 0, "noise"),          # odd width: copied
+    (640, 480, 3, 0, "blocks"),         # odd stride: copied
+    (640, 480, 0, 2, "blocks"),         # misaligned start: copied
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,pad,offset,kind", SHAPES)
+def test_in_place_equals_copy_equals_oracle(w, h, pad, offset, kind):
+    from oracle import orb_oracle as O
+    frames = np.stack([synth.frame(kind, w, h, 3 + i) for i in range(2)])
+    g_in, g_cp = _extractor(True), _extractor(False)
+    r_in, keep_in = _run_device(g_in, frames, pad, offset)          # (the images stay alive: level 0 is read from them again below)
+    r_cp, keep_cp = _run_device(g_cp, frames, pad, offset)
+    for i in range(len(frames)):
+        assert np.array_equal(r_in[i][0].view(np.uint32), r_cp[i][0].view(np.uint32)), (i, "keypoints")
+        assert np.array_equal(r_in[i][1], r_cp[i][1]), (i, "descriptors")
+    o = O.OracleExtractor(*PRM)
+    okp, odesc = o.extract(frames[1])
+    gk = r_in[1][0]
+    assert len(gk) == len(okp)
+    assert np.array_equal(gk[:, 0], okp["x"]) and np.array_equal(gk[:, 1], okp["y"])
+    assert np.array_equal(gk[:, 3], okp["angle"])
+    assert np.mean(np.all(r_in[1][1] == odesc, axis=1)) >= DESC_MIN_EXACT
+    if kind == "noise":
+        # the case is only worth its name if some level-0 keypoints do sit where the patch leaves the image
+        lvl0 = gk[gk[:, 5].view(np.int32) == 0]
+        assert np.any((lvl0[:, 0] < 22) | (lvl0[:, 1] < 21) | (lvl0[:, 0] > w - 23) | (lvl0[:, 1] > h - 23))
+    # the bordered pyramid asked for after the pass: level 0 is built from the images then (frame 1 of the last pass)
+    for l in (0, 1, 3):
+        assert np.array_equal(g_in.pyramid_level(l, frame=1, with_border=True), o.level(l, with_border=True)), l
+
+
+@pytest.mark.gpu
+def test_stereo_refinement_reads_level0_in_place():
+    """Extraction of both eyes and the stereo matching on device-resident pairs, in place against copied."""
+    import torch
+    from visual_slam_amd import orbhip
+    w, h, n = 752, 480, 3
+    lefts = np.stack([synth.frame("blocks", w, h, 11 + i) for i in range(n)])
+    rights = np.stack([np.roll(f, -9 - i, axis=1) for i, f in enumerate(lefts)])
+    dev = torch.device("cuda:0")
+    out = []
+    for inplace in (True, False):
+        gL, gR = _extractor(inplace, (1200, 1.2, 8, 20, 7)), _extractor(inplace, (1200, 1.2, 8, 20, 7))
+        L, R = torch.from_numpy(lefts).to(dev), torch.from_numpy(rights).to(dev)
+        cap = gL.max_keypoints()
+        mk = lambda: (torch.zeros((n, cap, 7), dtype=torch.float32, device=dev), torch.zeros((n, cap, 32), dtype=torch.uint8, device=dev),
+                      torch.zeros((n,), dtype=torch.int32, device=dev))
+        (kl, dl, cl), (kr, dr, cr) = mk(), mk()
+        ur = torch.full((n, cap), -7.0, dtype=torch.float32, device=dev)
+        dp = torch.full((n, cap), -7.0, dtype=torch.float32, device=dev)
+        nm = torch.zeros((n,), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        orbhip.extract_stereo_batch_device(gL, gR, L.data_ptr(), R.data_ptr(), n, w, h, w, w * h, kl.data_ptr(), dl.data_ptr(), cl.data_ptr(),
+                                           kr.data_ptr(), dr.data_ptr(), cr.data_ptr(), cap, 0.11, 47.9, ur.data_ptr(), dp.data_ptr(), nm.data_ptr())
+        gL.synchronize(); gR.synchronize()
+        torch.cuda.synchronize()
+        c = cl.cpu().numpy()
+        out.append((c, [ur[i, :c[i]].cpu().numpy() for i in range(n)], [dp[i, :c[i]].cpu().numpy() for i in range(n)], nm.cpu().numpy()))
+    (c0, u0, d0, m0), (c1, u1, d1, m1) = out
+    assert np.array_equal(c0, c1) and np.array_equal(m0, m1) and m0.min() > 50
+    for i in range(n):
+        assert np.array_equal(u0[i].view(np.uint32), u1[i].view(np.uint32)) and np.array_equal(d0[i].view(np.uint32), d1[i].view(np.uint32))

@@ -86,6 +86,18 @@ struct PlanDev {
     LevelGeom lv[ORB_MAX_LEVELS];
 };
 
+// Level 0 read in place. A gray input image already is level 0 (src/ORBextractor.cc:1107-1132 copies it into
+// a bordered buffer, but nothing on the path reads that border except the blur of keypoints within three
+// pixels of the detectable area's edge, which the descriptor kernel reflects itself). When the input
+// allows it (4-byte aligned rows) the kernels read level 0 from the caller's buffer and the copy into a
+// plane is skipped. org == nullptr: level 0 lives in its plane like the other levels.
+struct Level0View {
+    const uint8_t* org;               // pixel (0, 0) of frame 0
+    unsigned long long frame_bytes;   // distance between frames
+    int pitch;                        // distance between rows (multiple of 4)
+    int xlim;                         // bytes of every row that may be read (multiple of 4, >= w)
+};
+
 struct LevelKp {              // keypoint of one level after the quadtree, level coordinates
     uint16_t x, y;
     uint16_t score;

@@ -233,7 +233,7 @@ __device__ __forceinline__ void fast_score_queue2(const uint16_t* queue, int n, 
 // {x | y << 16 (relative to the detection window origin (16,16)), score} and its entry count.
 __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, const PlanDev* __restrict__ plan, int frames,
                                               uint2* __restrict__ seg, int* __restrict__ seg_count,
-                                              int* __restrict__ status, unsigned id_base) {
+                                              int* __restrict__ status, unsigned id_base, Level0View v0) {
     __shared__ __align__(16) uint8_t s_map[FT_MAP_ROWS * FT_P];
     __shared__ __align__(16) uint8_t s_img[FT_IMG_ROWS * FT_P];
     __shared__ uint16_t s_queue[4][FT_QUEUE];
@@ -262,10 +262,13 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
     const int xs = ORB_MINB + FT_COLS * bx;                    // level x of the tile's first output column
     const int y0 = ORB_EDGE + FT_ROWS * by;                    // level y of the tile's first row
     const int x_hi = g.w - ORB_EDGE, y_hi = g.h - ORB_EDGE;    // detectable area [19, x_hi) x [19, y_hi)
-    const int xg = xs - 4 + 4 * lane;                          // level x of this lane's pixel 0
-    const int col = ORB_OX + xg;                               // device column, multiple of 4
-    const bool col_ok = col + 8 <= g.pitch;                    // the lane's 12-byte window [col-4, col+8) exists
-    const uint8_t* plane = pyr + g.pyr_off + (size_t)f * g.plane_bytes;
+    const int xg = xs - 4 + 4 * lane;                          // level x of this lane's pixel 0 (multiple of 4, >= 12)
+    // where the level's pixel (0, 0) of this frame is: in its plane, or (level 0 read in place) in the caller's image
+    const bool inplace = level == 0 && v0.org != nullptr;      // uniform
+    const int pitch = inplace ? v0.pitch : g.pitch;
+    const uint8_t* org = inplace ? v0.org + (size_t)f * v0.frame_bytes
+                                 : pyr + g.pyr_off + (size_t)f * g.plane_bytes + (size_t)ORB_OY * g.pitch + ORB_OX;
+    const bool col_ok = xg + 4 <= (inplace ? v0.xlim : g.pitch - ORB_OX);   // the lane's dword exists
     // map row m <-> level row y0 - 1 + m; image tile row t <-> level row y0 - 4 + t
 
     for (int i = tid; i < FT_MAP_ROWS * FT_P / 8; i += 256) reinterpret_cast<uint2*>(s_map)[i] = make_uint2(0, 0);
@@ -289,13 +292,13 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
 
     uint16_t* queue = s_queue[wv];
     const v2s thr = {(short)min_th, (short)min_th};
-    const int y_last = g.h + ORB_EDGE - 1;                     // last row of the plane
-    // The lane's dword of level row y (wave-uniform: scalar row address + per-lane column). Rows past
-    // the plane repeat the last row and lanes past its width read column 0: neither feeds a scored pixel.
-    const uint32_t coff = col_ok ? (uint32_t)col : 0u;
+    const int y_last = g.h - 1;                                // last row of the level
+    // The lane's dword of level row y (wave-uniform: scalar row address + per-lane column; y >= 15). Rows
+    // past the level repeat its last row and lanes past its width read column 0: neither feeds a scored pixel.
+    const uint32_t coff = col_ok ? (uint32_t)xg : 0u;
     auto load_row = [&](int y) -> uint32_t {
-        const uint32_t off = (uint32_t)((ORB_OY + min(y, y_last)) * g.pitch) + coff;   // a plane is far below 4 GB
-        return *reinterpret_cast<const uint32_t*>(plane + off);
+        const uint32_t off = (uint32_t)(min(y, y_last) * pitch) + coff;   // a frame is far below 4 GB
+        return *reinterpret_cast<const uint32_t*>(org + off);
     };
     int pending = 0;                                           // queued pixels not scored yet (wave-uniform, < 128 between steps)
 #pragma unroll 1

@@ -326,13 +326,20 @@ typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 
 // src / dst: plane of frame 0 of the source / destination level (different levels never overlap,
 // which lets the loads of all rows be issued before the first store).
-template <bool NARROW>
+//
+// CLAMP (with NARROW): the source is an image read in place, whose rows end at byte `load_max + 12`
+// with nothing readable behind the last one. A lane whose 12-byte window would reach past that loads the
+// last 12 bytes of the row instead and shifts by up to 11 bytes; the host launches this variant for the
+// block columns (from bx0 on) that contain such lanes and the plain one for the rest.
+template <bool NARROW, bool CLAMP>
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                                LevelGeom gs, LevelGeom gd, const RsTab* __restrict__ tabs, int ndw) {
+                                                LevelGeom gs, LevelGeom gd, const RsTab* __restrict__ tabs, int ndw,
+                                                int bx0, int load_max) {
+    static_assert(NARROW || !CLAMP, "the clamped window is built for the narrow variant");
     // (An XCD-aware tile order cuts the bytes the L2s fetch by a third here but measures 6 % slower,
     // with the vector work of either variant: in plain dispatch order the XCDs stream through the same
     // region together and the cache behind the L2s absorbs the rows they share. Plain order it is.)
-    const int bx = blockIdx.x, by = blockIdx.y, f = blockIdx.z;
+    const int bx = blockIdx.x + bx0, by = blockIdx.y, f = blockIdx.z;
     const int c4 = bx * 64 + threadIdx.x;
     // a wave = one value of threadIdx.y: rows, their tap entries and row addresses are wave-uniform
     const int r0 = (by * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * RS_RPT;
@@ -344,8 +351,9 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     const uint32_t wgt[4] = {ta.y, ta.w, tb.y, tb.w};          // a0 | a1 << 16
     const int s00 = pos[0] & 0xFFFF, s01 = pos[1] & 0xFFFF, s02 = pos[2] & 0xFFFF, s03 = pos[3] & 0xFFFF;
     const int smin = min(min(s00, s01), min(s02, s03));
-    const int base = smin & ~3;
-    const uint32_t sh = (uint32_t)smin & 3;                    // NARROW: the loaded bytes are shifted so that byte 0 is column smin
+    const int base = CLAMP ? min(smin & ~3, load_max) : smin & ~3;
+    const uint32_t sh = (uint32_t)(smin - base);               // NARROW: the loaded bytes are shifted so that byte 0 is column smin (0..3; CLAMP: 0..11)
+    const bool sh4 = CLAMP && sh >= 4, sh8 = CLAMP && sh >= 8;
     uint32_t sel[4];
     bool hi[4];
 #pragma unroll
@@ -373,8 +381,14 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
         vb[k] = *reinterpret_cast<const Row12*>(S + ((uint32_t)((int)ty[k].s1 * gs.pitch) + lbase));
     }
     auto hpass = [&](const Row12& v, uint32_t (&h)[4]) {
-        const uint32_t lo = NARROW ? __builtin_amdgcn_alignbyte(v.b, v.a, sh) : 0u;
-        const uint32_t up = NARROW ? __builtin_amdgcn_alignbyte(v.c, v.b, sh) : 0u;
+        // CLAMP: whole dwords first (the bytes wanted start in dword sh / 4 of the window)
+        uint32_t da = v.a, db = v.b, dc = v.c;
+        if (CLAMP) {                                           // (two steps of one dword: stays in registers)
+            da = sh4 ? db : da; db = sh4 ? dc : db; dc = sh4 ? 0u : dc;
+            da = sh8 ? db : da; db = sh8 ? dc : db;
+        }
+        const uint32_t lo = NARROW ? __builtin_amdgcn_alignbyte(db, da, sh & 3) : 0u;
+        const uint32_t up = NARROW ? __builtin_amdgcn_alignbyte(dc, db, sh & 3) : 0u;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t p = NARROW ? __builtin_amdgcn_perm(up, lo, sel[i])
@@ -953,7 +967,7 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
                                                   float* __restrict__ out_kp,   // 7 floats per keypoint
                                                   uint8_t* __restrict__ out_desc, int* __restrict__ out_count,
                                                   int cap, int frame0, int* __restrict__ status,
-                                                  int frames, int ngroups, unsigned ngroups8_magic) {
+                                                  int frames, int ngroups, unsigned ngroups8_magic, Level0View v0) {
     __shared__ __align__(16) uint8_t s_raw[4][DS_RAW_BYTES];
     __shared__ __align__(16) uint16_t s_hp[4][DS_HP_ENTRIES];
     const int lane = threadIdx.x & 63;
@@ -988,20 +1002,46 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     const LevelGeom g = plan->lv[level];
     const LevelKp kp = lvl_kp[(size_t)f * plan->kp_per_frame + g.kp_off + j];
     const int kx = kp.x, ky = kp.y;
-    const uint8_t* P = pyr + g.pyr_off + (size_t)f * g.plane_bytes;
+    // pixel (0, 0) of the level: in its plane, or (level 0 read in place) in the caller's image
+    const bool inplace = level == 0 && v0.org != nullptr;
+    const int pitch = inplace ? v0.pitch : g.pitch;
+    const uint8_t* P = inplace ? v0.org + (size_t)f * v0.frame_bytes
+                               : pyr + g.pyr_off + (size_t)f * g.plane_bytes + (size_t)ORB_OY * g.pitch + ORB_OX;
     // ---- stage rows ky-22..ky+22, 13 aligned dwords per row starting at or before column kx-22
-    const int col0 = kx - 22 + ORB_OX;            // >= 29: keypoints are >= 19 px from the level edge
-    const int colA = col0 & ~3, off = col0 & 3;
+    const int col0 = kx - 22;                     // >= -3: keypoints are >= 19 px from the level edge
+    const int colA = col0 & ~3, off = col0 & 3;   // (a plane has 32 border columns left of x = 0 and 19 rows above y = 0)
     uint8_t* raw = s_raw[wv];
     // disc weights of this lane's row for the orientation step below (loaded early)
     const uint4* dwp = reinterpret_cast<const uint4*>(plan->disc_w[lane < 31 ? (lane < 15 ? 15 - lane : lane - 15) : 0]);
     const uint4 dw0 = dwp[0], dw1 = dwp[1], dw2 = dwp[2], dw3 = dwp[3];
     // (16 lanes per row, 13 of them active, 4 rows per trip: addresses advance by a constant; rows
     // 0 and 44 are never read: the moments use rows 7..37 and the blur rows 1..43)
-    {
-        const int sr = 1 + (lane >> 4), sc = lane & 15;
-        uint32_t goff = (uint32_t)((ky - 22 + ORB_OY + sr) * g.pitch + colA + sc * 4);   // a plane is far below 4 GB
-        uint8_t* dst = &raw[sr * DS_RAW_P + sc * 4];
+    const int sr = 1 + (lane >> 4), sc = lane & 15;
+    uint8_t* dst = &raw[sr * DS_RAW_P + sc * 4];
+    // An image read in place has no border around it: a keypoint whose patch leaves the image (the blur
+    // of its outermost test points reaches up to three pixels past the edge, BORDER_REFLECT_101 of
+    // src/ORBextractor.cc:1086) or whose aligned dwords leave the readable part of a row takes the
+    // byte-wise path below. Wave-uniform; the columns beyond kx+-22 of a staged row are never used.
+    if (inplace && !(kx >= 22 && kx + 22 <= g.w - 1 && colA + 52 <= v0.xlim && ky >= 21 && ky + 22 <= g.h - 1)) {
+        if (sc < 13) {
+#pragma unroll 1
+            for (int p = 0; p < 11; p++) {
+                const int r = 4 * p + sr;
+                if (r >= 45) break;
+                int y = ky - 22 + r;
+                y = y < 0 ? -y : y >= g.h ? 2 * (g.h - 1) - y : y;
+                uint32_t v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    int x = colA + 4 * sc + b;
+                    x = x < 0 ? -x : x >= g.w ? 2 * (g.w - 1) - x : x;
+                    v |= (uint32_t)P[y * pitch + x] << (8 * b);
+                }
+                *reinterpret_cast<uint32_t*>(dst + p * 4 * DS_RAW_P) = v;
+            }
+        }
+    } else {
+        int goff = (ky - 22 + sr) * pitch + colA + sc * 4;     // a frame is far below 2 GB
         if (sc < 13) {
 #pragma unroll
             for (int p = 0; p < 11; p++) {
@@ -1009,7 +1049,7 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
                     const uint32_t v = *reinterpret_cast<const uint32_t*>(P + goff);
                     *reinterpret_cast<uint32_t*>(dst + p * 4 * DS_RAW_P) = v;
                 }
-                goff += 4 * (uint32_t)g.pitch;
+                goff += 4 * pitch;
             }
         }
     }

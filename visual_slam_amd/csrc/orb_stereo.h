@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const PlanDev* __restrict_
                                                       int cap, float mb, float mbf,
                                                       float* __restrict__ uright, float* __restrict__ depth,
                                                       int* __restrict__ sad_out, int nframes, int ngroups,
-                                                      unsigned ngroups8_magic) {
+                                                      unsigned ngroups8_magic, Level0View v0l, Level0View v0r) {
     __shared__ int s_dist[4][12];
     __shared__ uint16_t s_cand[4][ST_CAND];
     const int lane = threadIdx.x & 63;
@@ -160,19 +160,23 @@ __global__ __launch_bounds__(256) void k_stereo_match(const PlanDev* __restrict_
         const int w = 5, L = 5;
         const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
         if (!(iniu < 0 || endu >= (float)g.w)) {
-            const uint8_t* PL = pyr_l + g.pyr_off + (size_t)f * g.plane_bytes + (size_t)ORB_OY * g.pitch + ORB_OX;
-            const uint8_t* PR = pyr_r + g.pyr_off + (size_t)f * g.plane_bytes + (size_t)ORB_OY * g.pitch + ORB_OX;
+            // pixel (0, 0) of the level on either side: in its plane, or (level 0 read in place) in the caller's image;
+            // every byte read below lies inside the level (rows around a keypoint, columns checked by iniu / endu)
+            const size_t plane_org = g.pyr_off + (size_t)f * g.plane_bytes + (size_t)ORB_OY * g.pitch + ORB_OX;
+            const bool inl = levelL == 0 && v0l.org != nullptr, inr = levelL == 0 && v0r.org != nullptr;
+            const uint8_t* PL = inl ? v0l.org + (size_t)f * v0l.frame_bytes : pyr_l + plane_org;
+            const uint8_t* PR = inr ? v0r.org + (size_t)f * v0r.frame_bytes : pyr_r + plane_org;
+            const int pitch_l = inl ? v0l.pitch : g.pitch, pitch_r = inr ? v0r.pitch : g.pitch;
             const int yl0 = (int)(scaledvL - w), xl0 = (int)(scaleduL - w), xr00 = (int)(scaleduR0 - L - w);
             int* dist = s_dist[wv];
             if (lane < 11) dist[lane] = 0;
             // (24-bit multiplies run at full rate; a plane is far below 2^24 rows x 2^24 bytes of pitch)
-            const int cL = PL[__mul24(yl0 + w, g.pitch) + xl0 + w];
+            const int cL = PL[__mul24(yl0 + w, pitch_l) + xl0 + w];
             for (int t = lane; t < 121; t += 64) {
                 const int i = __mul24(t, 745) >> 13, k = t - i * 11;   // t / 11 for t < 121: patch row, offset index (incR = k - 5)
-                const int rowoff = __mul24(yl0 + i, g.pitch);
-                const uint8_t* rl = PL + (rowoff + xl0);
-                const uint8_t* rr = PR + (rowoff + xr00 + k);
-                const int cR = PR[__mul24(yl0 + w, g.pitch) + xr00 + k + w];
+                const uint8_t* rl = PL + (__mul24(yl0 + i, pitch_l) + xl0);
+                const uint8_t* rr = PR + (__mul24(yl0 + i, pitch_r) + xr00 + k);
+                const int cR = PR[__mul24(yl0 + w, pitch_r) + xr00 + k + w];
                 // |(l - cL) - (r - cR)| = |(l + da) - (r + db)| with da = max(cR - cL, 0), db = max(cL - cR, 0):
                 // both sides stay non-negative, so the unsigned sum-of-absolute-differences instruction applies
                 const uint32_t da = (uint32_t)max(cR - cL, 0), db = (uint32_t)max(cL - cR, 0);

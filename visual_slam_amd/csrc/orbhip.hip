@@ -49,6 +49,13 @@ struct Workspace {
     uint32_t* d_qt_spill = nullptr;   // [frames][levels that spill][qt_spill_words] node arrays of k_quadtree that do not fit in LDS
     hipStream_t stream = nullptr;  // used when two passes are in flight
     hipEvent_t done = nullptr;
+    // Level 0 of the last pass on this workspace: read in place from the caller's images (v0.org set) or
+    // copied into its plane. A pass read in place remembers its source so that a later request for the
+    // bordered level-0 image (orbhip_pyramid_copy) can still build the plane.
+    Level0View v0 = {nullptr, 0, 0, 0};
+    const uint8_t* l0_src = nullptr;
+    size_t l0_row_stride = 0, l0_frame_stride = 0;
+    bool l0_in_plane = true;
 };
 const int kLanes = 4;
 const int kMinLaneFrames = 16;     // batches below twice this run as one pass on the caller's stream
@@ -105,6 +112,8 @@ struct orbhip_extractor {
     int plan_lanes = 0;            // workspaces allocated for the current plan
     int max_lanes = 1;             // ORBHIP_LANES=2..4: that many passes of a large batch in flight (a few % more throughput)
     hipEvent_t ev_fork = nullptr;
+    int inplace_l0 = 1;            // ORBHIP_INPLACE_LEVEL0=0: always copy gray input into the level-0 plane
+    std::vector<int> l1_base;      // per 4-pixel group of level 1's plane: 4-aligned first source column of its taps
     int overlap = 0;               // ORBHIP_OVERLAP=1: FAST of level 0 runs beside the resize chain on aux_stream
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_l0 = nullptr, ev_f0 = nullptr;
@@ -358,6 +367,14 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
             if (hi + 1 - lo > 7) narrow = 0;
         }
         P.lv[l].rs_narrow = narrow;
+        if (l == 1) {
+            e->l1_base.assign((size_t)ncol / 4, 0);
+            for (int c = 0; c < ncol; c += 4) {
+                int lo = 1 << 30;
+                for (int i = 0; i < 4; i++) lo = std::min(lo, (int)tabs[g.xtab_off + c + i].s0);
+                e->l1_base[(size_t)c / 4] = lo & ~3;
+            }
+        }
     }
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipMalloc(&e->d_plan, sizeof(PlanDev)));
@@ -401,22 +418,20 @@ struct SpanGuard {   // records a pair of events around a group of launches when
     }
 };
 
-// One pass: `frames` frames starting at device pointer d_imgs; outputs written at frame index frame0.
-// channels: 1 (gray), 3 or 4 (interleaved colour, converted to gray on the way in); rgb: channel 0 is red.
-int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_imgs, int frames, size_t row_stride,
-             size_t frame_stride, int channels, int rgb, float* d_kp, uint8_t* d_desc, int* d_counts, int cap, int frame0) {
+// Level 0 of `frames` frames into its plane (src/ORBextractor.cc:1113-1128 for level 0: the image inside
+// its 19-pixel reflected border), through the rectification maps or the gray conversion when asked.
+void launch_level0(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_imgs, int frames, size_t row_stride,
+                   size_t frame_stride, int channels, int rgb, bool use_maps) {
     const PlanDev& P = e->plan;
-    const int nl = P.nlevels;
     const dim3 blk2(64, 4);
     {
-        SpanGuard t(e, s, KC_LEVEL0);
         const LevelGeom& g = P.lv[0];
         const int n16 = (ORB_OX + g.w + ORB_EDGE + 15) / 16;
         const int aligned16 = ((uintptr_t)d_imgs % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0);
         // 16-byte groups [i_lo, i_hi) lie inside the image: straight dwordx4 copies when the
         // source is aligned; the groups that touch the border go through the reflecting byte path
         const int i_lo = ORB_OX / 16, i_hi = (ORB_OX + g.w) / 16;
-        if (e->d_map_x) {                                      // gray input through the rectification maps
+        if (use_maps && e->d_map_x) {                          // gray input through the rectification maps
             const int ndw = n16 * 4;
             hipLaunchKernelGGL(k_level0_remap, dim3((ndw + 63) / 64, (g.rows + 3) / 4, (frames + RM_FR - 1) / RM_FR), blk2, 0, s,
                                d_imgs, row_stride, frame_stride, frames, e->d_map_x, e->d_map_y, W.d_pyr, g, ndw,
@@ -441,6 +456,32 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
                                d_imgs, row_stride, frame_stride, W.d_pyr, g, n16, n16, n16);
         }
     }
+}
+
+// One pass: `frames` frames starting at device pointer d_imgs; outputs written at frame index frame0.
+// channels: 1 (gray), 3 or 4 (interleaved colour, converted to gray on the way in); rgb: channel 0 is red.
+// row_readable: bytes of every row (the last row of the last frame included) that belong to the buffer.
+int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_imgs, int frames, size_t row_stride,
+             size_t frame_stride, size_t row_readable, int channels, int rgb, float* d_kp, uint8_t* d_desc, int* d_counts,
+             int cap, int frame0) {
+    const PlanDev& P = e->plan;
+    const int nl = P.nlevels;
+    const dim3 blk2(64, 4);
+    // A gray image whose rows the kernels can read as aligned dwords already is level 0: FAST, the resize
+    // to level 1, the descriptors and the stereo refinement read it where it lies, and the copy into a
+    // bordered plane is skipped (the kernels never read past row_readable bytes of a row).
+    const int xlim = (int)(std::min(row_readable, row_stride) & ~(size_t)3);
+    const bool inplace = e->inplace_l0 && channels == 1 && !e->d_map_x && (uintptr_t)d_imgs % 4 == 0 && row_stride % 4 == 0 &&
+                         frame_stride % 4 == 0 && xlim >= P.lv[0].w && xlim >= 16 &&
+                         (unsigned long long)row_stride * (unsigned long long)P.lv[0].h < (1ull << 31) &&
+                         (nl == 1 || P.lv[1].rs_narrow);
+    W.v0 = inplace ? Level0View{d_imgs, (unsigned long long)frame_stride, (int)row_stride, xlim} : Level0View{nullptr, 0, 0, 0};
+    W.l0_src = d_imgs; W.l0_row_stride = row_stride; W.l0_frame_stride = frame_stride;
+    W.l0_in_plane = !inplace;
+    {
+        SpanGuard t(e, s, KC_LEVEL0);
+        if (!inplace) launch_level0(e, W, s, d_imgs, frames, row_stride, frame_stride, channels, rgb, true);
+    }
     // FAST is bound by vector issue, the resize chain by memory: with `overlap` level 0's FAST runs on
     // a second stream beside the chain and the remaining levels follow on the main stream
     const unsigned split = (e->overlap && nl > 1) ? P.fast_cum[1] * (unsigned)frames : 0u;
@@ -450,7 +491,7 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
         {
             SpanGuard t(e, e->aux_stream, KC_FAST);
             hipLaunchKernelGGL(k_fast, dim3(split), dim3(256), 0, e->aux_stream,
-                               W.d_pyr, e->d_plan, frames, W.d_seg, W.d_seg_count, e->d_status, 0u);
+                               W.d_pyr, e->d_plan, frames, W.d_seg, W.d_seg_count, e->d_status, 0u, W.v0);
         }
         HIP_TRY(e, hipEventRecord(e->ev_f0, e->aux_stream));
     }
@@ -458,18 +499,36 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
         SpanGuard t(e, s, KC_RESIZE);
         const LevelGeom& g = P.lv[l];
         const int ndw = (ORB_OX + g.w + ORB_EDGE + 3) / 4;
-        const dim3 grid((ndw + 63) / 64, (g.rows + 4 * RS_RPT - 1) / (4 * RS_RPT), frames);
-        if (g.rs_narrow)
-            hipLaunchKernelGGL(k_resize<true>, grid, blk2, 0, s, W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g,
-                               e->d_tabs, ndw);
+        const int nbx = (ndw + 63) / 64;
+        const dim3 grid(nbx, (g.rows + 4 * RS_RPT - 1) / (4 * RS_RPT), frames);
+        if (l == 1 && inplace) {
+            // the source is the caller's image: same kernel, the image's strides in place of the plane's, and the
+            // block columns with a lane whose 12-byte window would pass the readable part of a row take the
+            // clamping variant (normally the last one: the right edge and the border columns reflected onto it)
+            LevelGeom gs = P.lv[0];
+            gs.pitch = (int)row_stride;
+            gs.plane_bytes = frame_stride;
+            const uint8_t* src = reinterpret_cast<const uint8_t*>((uintptr_t)d_imgs - ((size_t)ORB_OY * row_stride + ORB_OX));
+            int first_clamp = nbx;
+            for (int c4 = 0; c4 < ndw && c4 < (int)e->l1_base.size(); c4++)
+                if (e->l1_base[(size_t)c4] + 12 > xlim) { first_clamp = c4 / 64; break; }
+            if (first_clamp > 0)
+                hipLaunchKernelGGL((k_resize<true, false>), dim3(first_clamp, grid.y, grid.z), blk2, 0, s, src, W.d_pyr + g.pyr_off, gs, g,
+                                   e->d_tabs, ndw, 0, 0);
+            if (first_clamp < nbx)
+                hipLaunchKernelGGL((k_resize<true, true>), dim3(nbx - first_clamp, grid.y, grid.z), blk2, 0, s, src, W.d_pyr + g.pyr_off, gs, g,
+                                   e->d_tabs, ndw, first_clamp, xlim - 12);
+        } else if (g.rs_narrow)
+            hipLaunchKernelGGL((k_resize<true, false>), grid, blk2, 0, s, W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g,
+                               e->d_tabs, ndw, 0, 0);
         else
-            hipLaunchKernelGGL(k_resize<false>, grid, blk2, 0, s, W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g,
-                               e->d_tabs, ndw);
+            hipLaunchKernelGGL((k_resize<false, false>), grid, blk2, 0, s, W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g,
+                               e->d_tabs, ndw, 0, 0);
     }
     if (P.fast_cum[nl] * (unsigned)frames > split) {           // all (remaining) levels in one launch
         SpanGuard t(e, s, KC_FAST);
         hipLaunchKernelGGL(k_fast, dim3(P.fast_cum[nl] * (unsigned)frames - split), dim3(256), 0, s,
-                           W.d_pyr, e->d_plan, frames, W.d_seg, W.d_seg_count, e->d_status, split);
+                           W.d_pyr, e->d_plan, frames, W.d_seg, W.d_seg_count, e->d_status, split, W.v0);
     }
     if (split) HIP_TRY(e, hipStreamWaitEvent(s, e->ev_f0, 0));
     {
@@ -491,7 +550,7 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
         if ((unsigned long long)nwg * (8ull * ngroups) >= (1ull << 32)) { e->err = "too many keypoints per pass"; return ORBHIP_ERR_CAPACITY; }
         hipLaunchKernelGGL(k_describe, dim3(nwg), dim3(256), 0, s,
                            e->d_plan, W.d_pyr, W.d_lvl_kp, W.d_lvl_cnt, d_kp, d_desc, d_counts, cap, frame0, e->d_status,
-                           frames, ngroups, grid_magic(8u * (unsigned)ngroups));
+                           frames, ngroups, grid_magic(8u * (unsigned)ngroups), W.v0);
     }
     HIP_TRY(e, hipGetLastError());
     e->last_pass_frames = frames;
@@ -591,6 +650,7 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
     if (!ok) { orbhip_destroy(e); return ORBHIP_ERR_HIP; }
     if (const char* v = std::getenv("ORBHIP_LANES")) e->max_lanes = std::min(kLanes, std::max(1, std::atoi(v)));
     if (const char* v = std::getenv("ORBHIP_OVERLAP")) e->overlap = std::atoi(v) != 0;
+    if (const char* v = std::getenv("ORBHIP_INPLACE_LEVEL0")) e->inplace_l0 = std::atoi(v) != 0;
     *out = e;
     return ORBHIP_OK;
 }
@@ -636,8 +696,8 @@ static int pass_budget(const orbhip_extractor* e, int width, int height) {
 }
 
 static int extract_device_impl(orbhip_extractor* e, const uint8_t* d_imgs, int nframes, int width, int height,
-                               size_t row_stride, size_t frame_stride, int channels, int rgb, orbhip_keypoint* d_kp,
-                               uint8_t* d_desc, int* d_counts, int cap, void* stream) {
+                               size_t row_stride, size_t frame_stride, size_t row_readable, int channels, int rgb,
+                               orbhip_keypoint* d_kp, uint8_t* d_desc, int* d_counts, int cap, void* stream) {
     if (!e || !d_kp || !d_desc || !d_counts || cap < 1 || nframes < 0 || (channels != 1 && channels != 3 && channels != 4))
         return ORBHIP_ERR_ARG;
     if (!d_imgs || width <= 0 || height <= 0 || nframes == 0) return ORBHIP_ERR_EMPTY;
@@ -675,7 +735,7 @@ static int extract_device_impl(orbhip_extractor* e, const uint8_t* d_imgs, int n
         const int n = std::min(chunk, nframes - f0);
         Workspace& W = e->ws[pass % lanes];
         int rc = run_pass(e, W, lanes > 1 ? W.stream : s, d_imgs + (size_t)f0 * frame_stride, n, row_stride, frame_stride,
-                          channels, rgb, reinterpret_cast<float*>(d_kp), d_desc, d_counts, cap, f0);
+                          row_readable, channels, rgb, reinterpret_cast<float*>(d_kp), d_desc, d_counts, cap, f0);
         if (rc) return rc;
     }
     if (lanes > 1)
@@ -690,15 +750,17 @@ static int extract_device_impl(orbhip_extractor* e, const uint8_t* d_imgs, int n
 int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int nframes, int width, int height,
                                 size_t row_stride, size_t frame_stride, orbhip_keypoint* d_kp, uint8_t* d_desc,
                                 int* d_counts, int cap, void* stream) {
-    return extract_device_impl(e, d_imgs, nframes, width, height, row_stride, frame_stride, 1, 0, d_kp, d_desc, d_counts, cap, stream);
+    // (the caller owns `width` bytes of every row; what lies behind the last row's is not known to be readable)
+    return extract_device_impl(e, d_imgs, nframes, width, height, row_stride, frame_stride, (size_t)std::max(width, 0), 1, 0, d_kp, d_desc,
+                               d_counts, cap, stream);
 }
 
 int orbhip_extract_batch_device_color(orbhip_extractor* e, const uint8_t* d_imgs, int nframes, int width, int height,
                                       size_t row_stride, size_t frame_stride, int channels, int rgb,
                                       orbhip_keypoint* d_kp, uint8_t* d_desc, int* d_counts, int cap, void* stream) {
     if (channels != 3 && channels != 4) return ORBHIP_ERR_ARG;
-    return extract_device_impl(e, d_imgs, nframes, width, height, row_stride, frame_stride, channels, rgb != 0, d_kp, d_desc,
-                               d_counts, cap, stream);
+    return extract_device_impl(e, d_imgs, nframes, width, height, row_stride, frame_stride, (size_t)std::max(width, 0) * channels,
+                               channels, rgb != 0, d_kp, d_desc, d_counts, cap, stream);
 }
 
 int orbhip_synchronize(orbhip_extractor* e) {
@@ -721,6 +783,12 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
     const size_t need = dev_frame * nframes;
     if (need > e->d_in_bytes) {
         HIP_TRY(e, hipDeviceSynchronize());
+        // a pass that read its level 0 in place from the old staging buffer loses it
+        for (Workspace& w : e->ws)
+            if (w.l0_src && w.l0_src >= e->d_in && w.l0_src < e->d_in + e->d_in_bytes) {
+                w.v0 = Level0View{nullptr, 0, 0, 0}; w.l0_src = nullptr; w.l0_in_plane = true;
+                e->last_pass_frames = 0;
+            }
         dfree(e->d_in);
         HIP_TRY(e, hipMalloc(&e->d_in, need));
         e->d_in_bytes = need;
@@ -756,7 +824,8 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
         else for (int y = 0; y < height; y++) std::memcpy(dst + (size_t)y * dev_row, src + (size_t)y * row_stride, (size_t)width * channels);
     }
     HIP_TRY(e, hipMemcpyAsync(e->d_in, e->h_in, need, hipMemcpyHostToDevice, e->stream));
-    int rc = extract_device_impl(e, e->d_in, nframes, width, height, dev_row, dev_frame, channels, rgb,
+    // (the staging buffer's rows are dev_row bytes long, all of them the library's own)
+    int rc = extract_device_impl(e, e->d_in, nframes, width, height, dev_row, dev_frame, dev_row, channels, rgb,
                                  reinterpret_cast<orbhip_keypoint*>(e->d_out_kp), e->d_out_desc, e->d_out_cnt, cap, nullptr);
     if (rc) return rc;
     uint8_t* h_cnt = e->h_out, *h_kp = e->h_out + cnt_bytes, *h_desc = h_kp + kp_bytes;
@@ -855,6 +924,15 @@ int orbhip_pyramid_copy(orbhip_extractor* e, int frame, int level, uint8_t* dst,
     // go row by row).
     if (e->h_pyr_gen != e->pass_gen || e->h_pyr_frame != frame) {
         HIP_TRY(e, hipDeviceSynchronize());
+        Workspace& W = e->ws[e->last_ws];
+        if (!W.l0_in_plane) {
+            // the pass read level 0 in place: build its bordered plane now, from the images the pass was given
+            // (they must still be there: see orbhip_extract_batch_device in the header)
+            if (!W.l0_src) return ORBHIP_ERR_STATE;
+            launch_level0(e, W, e->stream, W.l0_src, e->last_pass_frames, W.l0_row_stride, W.l0_frame_stride, 1, 0, false);
+            HIP_TRY(e, hipGetLastError());
+            W.l0_in_plane = true;
+        }
         if (e->pyr_bytes_per_frame > e->h_pyr_bytes) {
             if (e->h_pyr) (void)hipHostFree(e->h_pyr);
             e->h_pyr = nullptr; e->h_pyr_bytes = 0;
@@ -997,7 +1075,8 @@ static int stereo_batch_launch(orbhip_extractor* left, orbhip_extractor* right, 
                        left->d_plan, rinfo, bins, nbins, band, left->ws[left->last_ws].d_pyr, right->ws[right->last_ws].d_pyr,
                        reinterpret_cast<const StKp*>(d_kp_l), d_desc_l, d_cnt_l,
                        reinterpret_cast<const StKp*>(d_kp_r), d_desc_r, cap, mb, mbf, d_uright, d_depth, sad,
-                       nframes, ngroups, grid_magic(8u * (unsigned)ngroups));
+                       nframes, ngroups, grid_magic(8u * (unsigned)ngroups),
+                       left->ws[left->last_ws].v0, right->ws[right->last_ws].v0);
     hipLaunchKernelGGL(k_stereo_median, dim3(nframes), dim3(256), 0, s, d_cnt_l, cap, sad, d_uright, d_depth,
                        d_nmatch ? d_nmatch : sad + (size_t)nframes * cap);
     }
@@ -1128,10 +1207,10 @@ int orbhip_extract_stereo_batch_device(orbhip_extractor* left, orbhip_extractor*
     if (rc) return rc;
     for (int f0 = 0; f0 < nframes; f0 += chunk) {
         const int n = std::min(chunk, nframes - f0);
-        rc = run_pass(left, left->ws[0], s, d_imgs_l + (size_t)f0 * frame_stride, n, row_stride, frame_stride, 1, 0,
+        rc = run_pass(left, left->ws[0], s, d_imgs_l + (size_t)f0 * frame_stride, n, row_stride, frame_stride, (size_t)width, 1, 0,
                       reinterpret_cast<float*>(d_kp_l), d_desc_l, d_cnt_l, cap, f0);
         if (rc) return rc;
-        rc = run_pass(right, right->ws[0], s, d_imgs_r + (size_t)f0 * frame_stride, n, row_stride, frame_stride, 1, 0,
+        rc = run_pass(right, right->ws[0], s, d_imgs_r + (size_t)f0 * frame_stride, n, row_stride, frame_stride, (size_t)width, 1, 0,
                       reinterpret_cast<float*>(d_kp_r), d_desc_r, d_cnt_r, cap, f0);
         if (rc) { e->err = right->err; return rc; }
         const size_t o = (size_t)f0 * cap;
