@@ -305,10 +305,12 @@ __global__ __launch_bounds__(256) void k_level0_remap(const uint8_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// Level l from level l-1: cv::resize(8UC1, INTER_LINEAR) fixed-point arithmetic, border included
-// (a border pixel is the resized value at the reflected coordinate, which is what copyMakeBorder
-// copies there). The tap tables are built on the host exactly as OpenCV builds xofs/ialpha and
-// yofs/ibeta, and are indexed by DEVICE column / row, so the reflection is already folded in.
+// Level l from level l-1: cv::resize(8UC1, INTER_LINEAR) fixed-point arithmetic. The tap tables are
+// built on the host exactly as OpenCV builds xofs/ialpha and yofs/ibeta, and are indexed by DEVICE
+// column / row. (They also cover the plane's border, where the reflection of copyMakeBorder,
+// src/ORBextractor.cc:1120-1121, is folded in; the kernel does not produce the border: no kernel reads it,
+// the descriptor kernel reflects the few patches that reach past a level's edge itself, and
+// orbhip_pyramid_copy rebuilds it on the host.)
 //
 // A lane produces 4 adjacent pixels of RS_RPT consecutive rows. The source bytes of the 4 pixels
 // lie inside 12 bytes starting at a 4-aligned offset (checked on the host), so one dwordx3 load
@@ -329,21 +331,24 @@ typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 //
 // CLAMP (with NARROW): the source is an image read in place, whose rows end at byte `load_max + 12`
 // with nothing readable behind the last one. A lane whose 12-byte window would reach past that loads the
-// last 12 bytes of the row instead and shifts by up to 11 bytes; the host launches this variant for the
-// block columns (from bx0 on) that contain such lanes and the plain one for the rest.
+// last 12 bytes of the row instead and shifts by up to 11 bytes.
 template <bool NARROW, bool CLAMP>
-__global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                                LevelGeom gs, LevelGeom gd, const RsTab* __restrict__ tabs, int ndw,
-                                                int bx0, int load_max) {
+__device__ __forceinline__ void resize_rows(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                            const LevelGeom& gs, const LevelGeom& gd, const RsTab* __restrict__ tabs, int c4_end,
+                                            int load_max) {
     static_assert(NARROW || !CLAMP, "the clamped window is built for the narrow variant");
     // (An XCD-aware tile order cuts the bytes the L2s fetch by a third here but measures 6 % slower,
     // with the vector work of either variant: in plain dispatch order the XCDs stream through the same
     // region together and the cache behind the L2s absorbs the rows they share. Plain order it is.)
-    const int bx = blockIdx.x + bx0, by = blockIdx.y, f = blockIdx.z;
+    // Only the level itself is produced: plane columns ORB_OX .. ORB_OX + w - 1 (in groups of 4) and rows
+    // ORB_OY .. ORB_OY + h - 1. Nothing on the device reads a plane's border columns and rows.
+    const int bx = blockIdx.x, by = blockIdx.y, f = blockIdx.z;
+    // (block columns are aligned to 256 bytes of the plane's rows; the 8 lanes left of the level in the first one idle)
     const int c4 = bx * 64 + threadIdx.x;
+    const int row_end = ORB_OY + gd.h;
     // a wave = one value of threadIdx.y: rows, their tap entries and row addresses are wave-uniform
-    const int r0 = (by * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * RS_RPT;
-    if (c4 >= ndw || r0 >= gd.rows) return;
+    const int r0 = ORB_OY + (by * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * RS_RPT;
+    if (c4 < ORB_OX / 4 || c4 >= c4_end || r0 >= row_end) return;
     // x side: the same for every row
     const uint4* tx = reinterpret_cast<const uint4*>(tabs + gd.xtab_off + c4 * 4);
     const uint4 ta = tx[0], tb = tx[1];
@@ -371,14 +376,26 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     // y taps of the wave's rows (scalar loads), then every source row it needs, then the arithmetic
     RsTab ty[RS_RPT];
 #pragma unroll
-    for (int k = 0; k < RS_RPT; k++) ty[k] = ytab[min(r0 + k, gd.rows - 1)];
+    for (int k = 0; k < RS_RPT; k++) ty[k] = ytab[min(r0 + k, row_end - 1)];
     Row12 va[RS_RPT], vb[RS_RPT];
 #pragma unroll
     for (int k = 0; k < RS_RPT; k++) {
         // consecutive output rows usually share a source row: the upper row of k is the lower row of k-1
+#ifdef RS_EXP_NOLOAD
+        va[k].a = lbase * 3 + k; va[k].b = lbase ^ ty[k].s0; va[k].c = lbase + 77 * ty[k].s1;
+        vb[k].a = lbase * 5 + k; vb[k].b = lbase ^ ty[k].s1; vb[k].c = lbase + 31 * ty[k].s0;
+#elif defined(RS_EXP_DWORD)
+        if (k == 0 || ty[k].s0 != ty[k - 1].s1) {
+            va[k].a = *reinterpret_cast<const uint32_t*>(S + ((uint32_t)((int)ty[k].s0 * gs.pitch) + lbase));
+            va[k].b = va[k].a * 3; va[k].c = va[k].a + 5;
+        }
+        vb[k].a = *reinterpret_cast<const uint32_t*>(S + ((uint32_t)((int)ty[k].s1 * gs.pitch) + lbase));
+        vb[k].b = vb[k].a * 7; vb[k].c = vb[k].a + 9;
+#else
         if (k == 0 || ty[k].s0 != ty[k - 1].s1)
             va[k] = *reinterpret_cast<const Row12*>(S + ((uint32_t)((int)ty[k].s0 * gs.pitch) + lbase));
         vb[k] = *reinterpret_cast<const Row12*>(S + ((uint32_t)((int)ty[k].s1 * gs.pitch) + lbase));
+#endif
     }
     auto hpass = [&](const Row12& v, uint32_t (&h)[4]) {
         // CLAMP: whole dwords first (the bytes wanted start in dword sh / 4 of the window)
@@ -400,7 +417,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 #pragma unroll
     for (int k = 0; k < RS_RPT; k++) {
         const int r = r0 + k;
-        if (r >= gd.rows) break;
+        if (r >= row_end) break;
         uint32_t h0[4], h1[4];
         if (k > 0 && ty[k].s0 == ty[k - 1].s1) {
 #pragma unroll
@@ -410,21 +427,44 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
         }
         hpass(vb[k], h1);
         const uint32_t b0 = (uint32_t)ty[k].a0, b1 = (uint32_t)ty[k].a1;   // weights are never negative
-        uint32_t out = 0;
+        // 11-bit weight x 15-bit row value: the full-rate 24-bit multiply is exact.
+        // ((p0 >> 16) + (p1 >> 16) + 2) >> 2 with the 2 added as 2 << 16 before the shift of p0; the sum of
+        // the two upper halves is one add with 16-bit operand selects, written into one half of a register
+        // per pixel pair, so that the final shift is one packed instruction per pair and the four result
+        // bytes (each <= 255 by construction) are gathered by one byte permute
+        uint32_t pair[2];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             hprev[i] = h1[i];
-            // 11-bit weight x 15-bit row value: the full-rate 24-bit multiply is exact.
-            // ((p0 >> 16) + (p1 >> 16) + 2) >> 2 with the 2 added as 2 << 16 before the shift of p0; the
-            // sum of the two upper halves is one add with 16-bit operand selects
             const uint32_t p0 = __umul24(b0, h0[i]) + 0x20000u, p1 = __umul24(b1, h1[i]);
-            uint32_t sum;
-            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1"
-                : "=v"(sum) : "v"(p0), "v"(p1));
-            out |= (sum >> 2) << (8 * i);                      // <= 255 by construction
+            if (i & 1)
+                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1"
+                    : "+v"(pair[i >> 1]) : "v"(p0), "v"(p1));
+            else
+                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1"
+                    : "=v"(pair[i >> 1]) : "v"(p0), "v"(p1));
         }
+        const v2us two = {2, 2};
+        const uint32_t q01 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(v2us, pair[0]) >> two);
+        const uint32_t q23 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(v2us, pair[1]) >> two);
+        uint32_t out = __builtin_amdgcn_perm(q23, q01, 0x06040200u);
+#ifdef RS_EXP_NOALU
+        out = vb[k].a ^ vb[k].b ^ vb[k].c ^ ((k == 0 || ty[k].s0 != ty[k - 1].s1) ? va[k].a : 0u);
+#endif
         *reinterpret_cast<uint32_t*>(D + ((uint32_t)(r * gd.pitch) + 4u * (uint32_t)c4)) = out;
     }
+}
+
+// EDGE: the source is an image read in place (see resize_rows): the block columns from `first_clamp` on
+// contain lanes whose window would pass the readable part of a row and run the clamping code, the
+// others the plain code (a branch uniform over the workgroup).
+template <bool NARROW, bool EDGE>
+__global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                LevelGeom gs, LevelGeom gd, const RsTab* __restrict__ tabs, int c4_end,
+                                                int first_clamp, int load_max) {
+    static_assert(NARROW || !EDGE, "an image is read in place by the narrow variant only");
+    if (EDGE && (int)blockIdx.x >= first_clamp) resize_rows<NARROW, NARROW && EDGE>(src, dst, gs, gd, tabs, c4_end, load_max);
+    else resize_rows<NARROW, false>(src, dst, gs, gd, tabs, c4_end, load_max);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1018,11 +1058,12 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     // 0 and 44 are never read: the moments use rows 7..37 and the blur rows 1..43)
     const int sr = 1 + (lane >> 4), sc = lane & 15;
     uint8_t* dst = &raw[sr * DS_RAW_P + sc * 4];
-    // An image read in place has no border around it: a keypoint whose patch leaves the image (the blur
-    // of its outermost test points reaches up to three pixels past the edge, BORDER_REFLECT_101 of
-    // src/ORBextractor.cc:1086) or whose aligned dwords leave the readable part of a row takes the
-    // byte-wise path below. Wave-uniform; the columns beyond kx+-22 of a staged row are never used.
-    if (inplace && !(kx >= 22 && kx + 22 <= g.w - 1 && colA + 52 <= v0.xlim && ky >= 21 && ky + 22 <= g.h - 1)) {
+    // Only the level's own pixels are stored: a keypoint whose patch leaves the level (the blur of its
+    // outermost test points reaches up to three pixels past the edge, BORDER_REFLECT_101 of
+    // src/ORBextractor.cc:1086) or, in an image read in place, whose aligned dwords leave the readable
+    // part of a row takes the byte-wise reflecting path below. Wave-uniform; the columns beyond kx+-22
+    // of a staged row are never used (in a plane they exist: 32 columns left of x = 0, at least 19 right of w).
+    if (!(kx >= 22 && kx + 22 <= g.w - 1 && ky >= 21 && ky + 22 <= g.h - 1) || (inplace && colA + 52 > v0.xlim)) {
         if (sc < 13) {
 #pragma unroll 1
             for (int p = 0; p < 11; p++) {

@@ -498,32 +498,28 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
     for (int l = 1; l < nl; l++) {
         SpanGuard t(e, s, KC_RESIZE);
         const LevelGeom& g = P.lv[l];
-        const int ndw = (ORB_OX + g.w + ORB_EDGE + 3) / 4;
-        const int nbx = (ndw + 63) / 64;
-        const dim3 grid(nbx, (g.rows + 4 * RS_RPT - 1) / (4 * RS_RPT), frames);
+        // (only the level itself: 4-pixel groups ORB_OX / 4 .. c4_end - 1 of the plane's rows ORB_OY .. ORB_OY + h - 1)
+        const int c4_begin = ORB_OX / 4, c4_end = c4_begin + (g.w + 3) / 4;
+        const int nbx = (c4_end + 63) / 64;
+        const dim3 grid(nbx, (g.h + 4 * RS_RPT - 1) / (4 * RS_RPT), frames);
         if (l == 1 && inplace) {
             // the source is the caller's image: same kernel, the image's strides in place of the plane's, and the
-            // block columns with a lane whose 12-byte window would pass the readable part of a row take the
-            // clamping variant (normally the last one: the right edge and the border columns reflected onto it)
+            // block columns with a lane whose 12-byte window would pass the readable part of a row run the
+            // clamping code (normally the last one: the right edge and the border columns reflected onto it)
             LevelGeom gs = P.lv[0];
             gs.pitch = (int)row_stride;
             gs.plane_bytes = frame_stride;
             const uint8_t* src = reinterpret_cast<const uint8_t*>((uintptr_t)d_imgs - ((size_t)ORB_OY * row_stride + ORB_OX));
             int first_clamp = nbx;
-            for (int c4 = 0; c4 < ndw && c4 < (int)e->l1_base.size(); c4++)
+            for (int c4 = c4_begin; c4 < c4_end && c4 < (int)e->l1_base.size(); c4++)
                 if (e->l1_base[(size_t)c4] + 12 > xlim) { first_clamp = c4 / 64; break; }
-            if (first_clamp > 0)
-                hipLaunchKernelGGL((k_resize<true, false>), dim3(first_clamp, grid.y, grid.z), blk2, 0, s, src, W.d_pyr + g.pyr_off, gs, g,
-                                   e->d_tabs, ndw, 0, 0);
-            if (first_clamp < nbx)
-                hipLaunchKernelGGL((k_resize<true, true>), dim3(nbx - first_clamp, grid.y, grid.z), blk2, 0, s, src, W.d_pyr + g.pyr_off, gs, g,
-                                   e->d_tabs, ndw, first_clamp, xlim - 12);
+            hipLaunchKernelGGL((k_resize<true, true>), grid, blk2, 0, s, src, W.d_pyr + g.pyr_off, gs, g, e->d_tabs, c4_end, first_clamp, xlim - 12);
         } else if (g.rs_narrow)
             hipLaunchKernelGGL((k_resize<true, false>), grid, blk2, 0, s, W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g,
-                               e->d_tabs, ndw, 0, 0);
+                               e->d_tabs, c4_end, 0, 0);
         else
             hipLaunchKernelGGL((k_resize<false, false>), grid, blk2, 0, s, W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g,
-                               e->d_tabs, ndw, 0, 0);
+                               e->d_tabs, c4_end, 0, 0);
     }
     if (P.fast_cum[nl] * (unsigned)frames > split) {           // all (remaining) levels in one launch
         SpanGuard t(e, s, KC_FAST);
@@ -952,10 +948,18 @@ int orbhip_pyramid_copy(orbhip_extractor* e, int frame, int level, uint8_t* dst,
     }
     size_t off = 0;
     for (int l = 0; l < level; l++) off += e->plan.lv[l].plane_bytes;
-    const int rows = g.h + 2 * b;
-    const uint8_t* src = e->h_pyr + off + (size_t)(ORB_OY - b) * g.pitch + (ORB_OX - b);
-    for (int y = 0; y < rows; y++)
-        std::memcpy(dst + (size_t)y * dst_stride, src + (size_t)y * g.pitch, (size_t)(g.w + 2 * b));
+    // The planes hold the levels themselves; the 19-pixel border the reference keeps around every level
+    // (copyMakeBorder with BORDER_REFLECT_101, src/ORBextractor.cc:1120-1128) is rebuilt here.
+    const uint8_t* lvl = e->h_pyr + off + (size_t)ORB_OY * g.pitch + ORB_OX;
+    for (int y = -b; y < g.h + b; y++) {
+        const uint8_t* srow = lvl + (size_t)reflect101_host(y, g.h) * g.pitch;
+        uint8_t* drow = dst + (size_t)(y + b) * dst_stride;
+        std::memcpy(drow + b, srow, (size_t)g.w);
+        for (int x = 1; x <= b; x++) {
+            drow[b - x] = srow[reflect101_host(-x, g.w)];
+            drow[b + g.w - 1 + x] = srow[reflect101_host(g.w - 1 + x, g.w)];
+        }
+    }
     return ORBHIP_OK;
 }
 
