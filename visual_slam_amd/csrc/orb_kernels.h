@@ -1058,12 +1058,13 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     // 0 and 44 are never read: the moments use rows 7..37 and the blur rows 1..43)
     const int sr = 1 + (lane >> 4), sc = lane & 15;
     uint8_t* dst = &raw[sr * DS_RAW_P + sc * 4];
-    // Only the level's own pixels are stored: a keypoint whose patch leaves the level (the blur of its
+    // Only the level's own pixels are stored: where a patch leaves the level (the blur of a keypoint's
     // outermost test points reaches up to three pixels past the edge, BORDER_REFLECT_101 of
-    // src/ORBextractor.cc:1086) or, in an image read in place, whose aligned dwords leave the readable
-    // part of a row takes the byte-wise reflecting path below. Wave-uniform; the columns beyond kx+-22
-    // of a staged row are never used (in a plane they exist: 32 columns left of x = 0, at least 19 right of w).
-    if (!(kx >= 22 && kx + 22 <= g.w - 1 && ky >= 21 && ky + 22 <= g.h - 1) || (inplace && colA + 52 > v0.xlim)) {
+    // src/ORBextractor.cc:1086) the missing rows and columns are rebuilt by reflection. Wave-uniform
+    // branches; the columns beyond kx+-22 of a staged row are never used.
+    const bool edge = !(kx >= 22 && kx + 22 <= g.w - 1 && ky >= 21 && ky + 22 <= g.h - 1);
+    if (inplace && (edge || colA + 52 > v0.xlim)) {
+        // an image read in place has nothing readable around it: byte by byte, reflecting the coordinates
         if (sc < 13) {
 #pragma unroll 1
             for (int p = 0; p < 11; p++) {
@@ -1091,6 +1092,28 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
                     *reinterpret_cast<uint32_t*>(dst + p * 4 * DS_RAW_P) = v;
                 }
                 goff += 4 * pitch;
+            }
+        }
+        if (edge) {
+            // A plane has room around the level (32 columns left of x = 0, at least 19 right of w, 19 rows
+            // above and below), so the loads above were in bounds, but nothing is stored there: the (at most
+            // three) rows and columns of the patch outside the level are copied from their mirror images
+            // inside the staged patch, rows first, so that the corners come out right. LDS operations of
+            // a wave complete in order.
+            uint32_t* raw32 = reinterpret_cast<uint32_t*>(raw);
+            const int j = lane >> 4;                           // 0..3: which row from the top / bottom of the patch
+            if (sc < 13) {
+                const int rt = 1 + j, yt = ky - 22 + rt;       // mirror of row y < 0 is row -y: staged row rt - 2 * yt
+                if (yt < 0) raw32[rt * (DS_RAW_P / 4) + sc] = raw32[(rt - 2 * yt) * (DS_RAW_P / 4) + sc];
+                const int rb = 44 - j, yb = ky - 22 + rb;      // mirror of row y >= h is row 2 (h - 1) - y
+                if (yb >= g.h) raw32[rb * (DS_RAW_P / 4) + sc] = raw32[(rb - 2 * (yb - (g.h - 1))) * (DS_RAW_P / 4) + sc];
+            }
+            for (int t = lane; t < 3 * 44; t += 64) {
+                const int jj = (t >= 88) ? 2 : (t >= 44) ? 1 : 0;
+                uint8_t* row = raw + (1 + t - 44 * jj) * DS_RAW_P;
+                const int xl = -1 - jj, xr = g.w + jj;         // columns left / right of the level
+                if (xl >= colA) row[xl - colA] = row[-xl - colA];
+                if (xr - colA < DS_RAW_P) row[xr - colA] = row[2 * (g.w - 1) - xr - colA];
             }
         }
     }
