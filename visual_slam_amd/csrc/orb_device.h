@@ -37,7 +37,11 @@ struct LevelGeom {
     unsigned wcell_magic, hcell_magic;   // floor(2^32/d)+1: n/d == umulhi(n, magic) for n < 65536, 1 < d < 65536
     unsigned wcell_m22, hcell_m22;       // ceil(2^22/d): n/d == (n * m) >> 22 for n * d < 2^22, a 24-bit multiply
     // FAST output segments
-    int ntx, nty;             // tiles of k_fast in x and y; 4 segments per tile
+    int ntx, nty;             // tile columns and tile rows of k_fast (248 x 32 pixels each)
+    // Workgroups of k_fast per frame: fast_ntx_plain * nty plain tiles, then the packed tiles of the last
+    // tile column (fast_bands tile rows each) when that column is narrow enough to hold two or more bands
+    // of fast_lpb lanes in a wave (fast_bands == 1: no packing, fast_ntx_plain == ntx). 4 segments per workgroup.
+    int fast_ntiles, fast_ntx_plain, fast_bands, fast_lpb;
     unsigned long long seg_off;      // entry offset of this level's first segment inside a frame's segment block
     int segc_off;             // offset of this level's first segment count inside a frame's count block
     // compact keys of the quadtree
@@ -75,14 +79,14 @@ struct PlanDev {
     // pattern lies inside a circle of radius sqrt(338)): byte offset of the item's first pixel in the
     // staged patch | byte offset of its first sum << 16; padded with repeats to ORB_HP_ITEMS.
     uint32_t hp_items[ORB_HP_ITEMS];
-    // k_fast handles all levels in one launch: workgroups [fast_cum[l] * frames, fast_cum[l+1] * frames)
-    // belong to level l (fast_cum = running sum of tiles per frame); magics for the divisions by the
-    // tiles per frame and the tiles per row of a level (grid_magic)
+    // k_fast handles all levels in one launch per kind of tile: workgroups [fast_cum[k][l] * frames,
+    // fast_cum[k][l+1] * frames) belong to level l (running sum of that kind's tiles per frame); magics for
+    // the divisions by the tiles per frame and the plain tiles per row of a level (grid_magic)
     // k_quadtree: slot of a level's node arrays in the global spill buffer, or -1 when they fit in LDS
     int qt_spill_slot[ORB_MAX_LEVELS];
     int qt_nspill;                       // levels with a slot
-    uint32_t fast_cum[ORB_MAX_LEVELS + 1];
-    uint32_t fast_tiles_magic[ORB_MAX_LEVELS], fast_ntx_magic[ORB_MAX_LEVELS];
+    uint32_t fast_cum[2][ORB_MAX_LEVELS + 1];        // [0] plain tiles, [1] packed tiles (their own launch)
+    uint32_t fast_tiles_magic[2][ORB_MAX_LEVELS], fast_ntx_magic[ORB_MAX_LEVELS];
     LevelGeom lv[ORB_MAX_LEVELS];
 };
 

@@ -170,17 +170,33 @@ __device__ __forceinline__ void fast_list_append(bool hit_a, uint32_t code_a, bo
     }
 }
 
-// true for a map position that is an output pixel of the tile (map rows 1..32, tile columns 4..251);
-// the rest of the map is the one-pixel halo that only serves as neighbours
-__device__ __forceinline__ bool fast_is_output(int row, int xl) {
-    return (unsigned)(row - 1) < (unsigned)FT_ROWS && (unsigned)(xl - 4) < (unsigned)FT_COLS;
+// Lanes of a tile. A plain tile is one band of 64 lanes (62 with output columns between two halo lanes).
+// PACKED: the last tile column of a level is often much narrower than 248 pixels; there the 64 lanes hold
+// several bands of `lpb` lanes (output lanes between two halo lanes again), each band the same columns of
+// another tile row (band b <-> tile row first + b, 32 level rows further down), so that one workgroup does
+// the work of several nearly empty ones. LDS tile, map, queue and list are indexed by lane column and
+// tile row exactly as in a plain tile; only the translation to level coordinates knows about bands.
+struct FastBands {
+    int lpb;                 // lanes per band
+    int nbands;              // bands of this tile that exist (the last packed tile of a level may have fewer)
+    unsigned magic;          // ceil(2^16 / lpb): lane / lpb == (lane * magic) >> 16 for lane < 64
+};
+
+// true for a map position that is an output pixel of the tile (map rows 1..32, tile columns 4..251, or
+// the columns of a band's inner lanes); the rest of the map is the one-pixel halo that only serves as neighbours
+template <bool PACKED>
+__device__ __forceinline__ bool fast_is_output(int row, int xl, const FastBands& fb) {
+    if (!PACKED) return (unsigned)(row - 1) < (unsigned)FT_ROWS && (unsigned)(xl - 4) < (unsigned)FT_COLS;
+    const int ln = xl >> 2, li = ln - __mul24((int)(__umul24((uint32_t)ln, fb.magic) >> 16), fb.lpb);
+    return (unsigned)(row - 1) < (unsigned)FT_ROWS && (unsigned)(li - 1) < (unsigned)(fb.lpb - 2);
 }
 
 // Scores `n` (<= 64) queued pixels, one per lane, from the LDS image tile into the tile map.
 // Queue entry: step << 11 | lane << 5 | b with b = 8 * pixel + 7 - row (the sieve's verdict word);
 // map row = m0 + FT_GROUP * step + row, image tile row = map row + 3.
+template <bool PACKED>
 __device__ __forceinline__ void fast_score_queue(const uint16_t* queue, int n, int lane, int m0, const uint8_t* img,
-                                                 int min_th, uint8_t* map, uint16_t* list, int* nlist) {
+                                                 int min_th, uint8_t* map, uint16_t* list, int* nlist, const FastBands& fb) {
     bool hit = false;
     uint32_t code = 0;
     if (lane < n) {
@@ -196,7 +212,7 @@ __device__ __forceinline__ void fast_score_queue(const uint16_t* queue, int n, i
         const int s = fast_score16(c[0], p);
         if (s >= min_th) {
             map[__mul24(row, FT_P) + xl] = (uint8_t)s;
-            hit = fast_is_output(row, xl);
+            hit = fast_is_output<PACKED>(row, xl, fb);
             code = (uint32_t)(row << 8 | xl);
         }
     }
@@ -205,8 +221,9 @@ __device__ __forceinline__ void fast_score_queue(const uint16_t* queue, int n, i
 
 // Scores `n` (64 < n <= 128) queued pixels, two per lane (entries lane and lane + 64), with packed
 // 16-bit arithmetic. A lane without a second entry scores its first one twice.
+template <bool PACKED>
 __device__ __forceinline__ void fast_score_queue2(const uint16_t* queue, int n, int lane, int m0, const uint8_t* img,
-                                                  int min_th, uint8_t* map, uint16_t* list, int* nlist) {
+                                                  int min_th, uint8_t* map, uint16_t* list, int* nlist, const FastBands& fb) {
     const bool two = lane + 64 < n;
     const uint32_t ea = queue[lane], eb = queue[two ? lane + 64 : lane];
     const int xa = (int)((ea >> 3) & 0xFC) + (int)((ea >> 3) & 3), xb = (int)((eb >> 3) & 0xFC) + (int)((eb >> 3) & 3);
@@ -224,52 +241,34 @@ __device__ __forceinline__ void fast_score_queue2(const uint16_t* queue, int n, 
     const bool sa = s.x >= min_th, sb = two && s.y >= min_th;
     if (sa) map[pa] = (uint8_t)s.x;
     if (sb) map[pb] = (uint8_t)s.y;
-    fast_list_append(sa && fast_is_output(ra, xa), (uint32_t)(ra << 8 | xa), sb && fast_is_output(rb, xb), (uint32_t)(rb << 8 | xb),
-                     lane, list, nlist);
+    fast_list_append(sa && fast_is_output<PACKED>(ra, xa, fb), (uint32_t)(ra << 8 | xa), sb && fast_is_output<PACKED>(rb, xb, fb),
+                     (uint32_t)(rb << 8 | xb), lane, list, nlist);
 }
 
-// Grid: one dimension, all tiles of all levels of all frames (level-major, then frame, tile row,
-// tile column: the large levels start first). Output: segment (tile, wave) of FT_SEGCAP entries
-// {x | y << 16 (relative to the detection window origin (16,16)), score} and its entry count.
-__global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, const PlanDev* __restrict__ plan, int frames,
-                                              uint2* __restrict__ seg, int* __restrict__ seg_count,
-                                              int* __restrict__ status, unsigned id_base, Level0View v0) {
-    __shared__ __align__(16) uint8_t s_map[FT_MAP_ROWS * FT_P];
-    __shared__ __align__(16) uint8_t s_img[FT_IMG_ROWS * FT_P];
-    __shared__ uint16_t s_queue[4][FT_QUEUE];
-    __shared__ uint16_t s_list[FT_LIST];                       // scored output pixels of the tile
-    __shared__ int s_nlist;
+// One tile. xs / y0: level x of the tile's first output column, level y of its first row (of band 0).
+// tile: index of the tile inside its level (its output segments are 4 * tile .. 4 * tile + 3).
+template <bool PACKED>
+__device__ __forceinline__ void fast_tile(const LevelGeom& g, const uint8_t* __restrict__ org, int pitch, int xlimit, int xs, int y0,
+                                          int tile, const FastBands fb, int min_th, uint2* __restrict__ out, int* __restrict__ out_count,
+                                          int* __restrict__ status, uint8_t* s_map, uint8_t* s_img, uint16_t (*s_queue)[FT_QUEUE],
+                                          uint16_t* s_list, int* s_nlist_p) {
+    int& s_nlist = *s_nlist_p;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: row bookkeeping runs on the scalar unit
-    // which tile: everything here is uniform over the workgroup (scalar unit)
-    // The levels take consecutive ranges of the dispatch order; inside its level's range a workgroup
-    // is remapped so that neighbouring tiles (shared halo rows / lines) share an L2 and every level
-    // is spread over all XCDs (tiles of different levels do not cost the same).
-    const unsigned id = id_base + blockIdx.x;                  // a launch may cover a sub-range of the levels
-    int level = 0;
-    while (level + 1 < plan->nlevels && id >= plan->fast_cum[level + 1] * (unsigned)frames) level++;
-    const LevelGeom g = plan->lv[level];
-    const unsigned rem = xcd_contiguous(id - plan->fast_cum[level] * (unsigned)frames, (unsigned)(g.ntx * g.nty * frames));
-    const unsigned mt = plan->fast_tiles_magic[level], mx = plan->fast_ntx_magic[level];
-    const int f = (int)(mt ? __umulhi(rem, mt) : rem);
-    const unsigned t = rem - (unsigned)f * (unsigned)(g.ntx * g.nty);
-    const int by = (int)(mx ? __umulhi(t, mx) : t);
-    const int bx = (int)(t - (unsigned)by * (unsigned)g.ntx);
-    const int min_th = plan->min_th;
-    const unsigned long long seg_per_frame = plan->seg_per_frame;
-    const int segc_per_frame = plan->segc_per_frame;
-    const int xs = ORB_MINB + FT_COLS * bx;                    // level x of the tile's first output column
-    const int y0 = ORB_EDGE + FT_ROWS * by;                    // level y of the tile's first row
+    // the lane's band and its place inside it
+    int band = 0, li = lane;
+    bool band_ok = true;
+    if (PACKED) {
+        band = (int)(__umul24((uint32_t)lane, fb.magic) >> 16);
+        li = lane - __mul24(band, fb.lpb);
+        band_ok = band < fb.nbands;
+    }
+    const int last_li = PACKED ? fb.lpb - 1 : 63;
     const int x_hi = g.w - ORB_EDGE, y_hi = g.h - ORB_EDGE;    // detectable area [19, x_hi) x [19, y_hi)
-    const int xg = xs - 4 + 4 * lane;                          // level x of this lane's pixel 0 (multiple of 4, >= 12)
-    // where the level's pixel (0, 0) of this frame is: in its plane, or (level 0 read in place) in the caller's image
-    const bool inplace = level == 0 && v0.org != nullptr;      // uniform
-    const int pitch = inplace ? v0.pitch : g.pitch;
-    const uint8_t* org = inplace ? v0.org + (size_t)f * v0.frame_bytes
-                                 : pyr + g.pyr_off + (size_t)f * g.plane_bytes + (size_t)ORB_OY * g.pitch + ORB_OX;
-    const bool col_ok = xg + 4 <= (inplace ? v0.xlim : g.pitch - ORB_OX);   // the lane's dword exists
-    // map row m <-> level row y0 - 1 + m; image tile row t <-> level row y0 - 4 + t
+    const int xg = xs - 4 + 4 * li;                            // level x of this lane's pixel 0 (multiple of 4, >= 12)
+    const bool col_ok = band_ok && xg + 4 <= xlimit;           // the lane's dword exists
+    // map row m <-> level row y0 - 1 + m (+ 32 * band); image tile row t <-> level row y0 - 4 + t (+ 32 * band)
 
     for (int i = tid; i < FT_MAP_ROWS * FT_P / 8; i += 256) reinterpret_cast<uint2*>(s_map)[i] = make_uint2(0, 0);
     if (tid == 0) s_nlist = 0;
@@ -278,12 +277,12 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
     const int m0 = wv < 2 ? 9 * wv : 2 + 8 * wv;
     const int nrows = wv < 2 ? 9 : 8;
     // bit i: pixel i is scored: inside the detectable columns and, for the halo lanes, only the
-    // one column that neighbours an output column (tile columns 3 and 252)
+    // one column that neighbours an output column (tile columns 3 and 252, or the band's)
     uint32_t ok_bits = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int xl = 4 * lane + i;
-        ok_bits |= (uint32_t)(xg + i >= ORB_EDGE && xg + i < x_hi && xl >= 3 && xl <= 252) << i;
+        const int xl = 4 * li + i;
+        ok_bits |= (uint32_t)(band_ok && xg + i >= ORB_EDGE && xg + i < x_hi && xl >= 3 && xl <= 4 * last_li) << i;
     }
     // the same as a mask over the sieve's verdict word (one byte per pixel)
     const uint32_t ok_mask = ((ok_bits & 1) ? 0xFFu : 0u) | ((ok_bits & 2) ? 0xFF00u : 0u) |
@@ -293,11 +292,13 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
     uint16_t* queue = s_queue[wv];
     const v2s thr = {(short)min_th, (short)min_th};
     const int y_last = g.h - 1;                                // last row of the level
-    // The lane's dword of level row y (wave-uniform: scalar row address + per-lane column; y >= 15). Rows
-    // past the level repeat its last row and lanes past its width read column 0: neither feeds a scored pixel.
-    const uint32_t coff = col_ok ? (uint32_t)xg : 0u;
+    // The lane's dword of level row y (wave-uniform: scalar row address + per-lane column and band offset;
+    // y >= 15). Rows past the level repeat its last row and lanes past its width read column 0: neither
+    // feeds a scored pixel. PACKED (planes only): no clamp, a band's rows end at most 15 rows below the
+    // level, inside the plane; lanes of a band that does not exist read band 0's rows.
+    const uint32_t coff = col_ok ? (uint32_t)xg + (PACKED ? (uint32_t)(__mul24(band, FT_ROWS) * pitch) : 0u) : 0u;
     auto load_row = [&](int y) -> uint32_t {
-        const uint32_t off = (uint32_t)(min(y, y_last) * pitch) + coff;   // a frame is far below 4 GB
+        const uint32_t off = (uint32_t)((PACKED ? y : min(y, y_last)) * pitch) + coff;   // a frame is far below 4 GB
         return *reinterpret_cast<const uint32_t*>(org + off);
     };
     int pending = 0;                                           // queued pixels not scored yet (wave-uniform, < 128 between steps)
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
 #pragma unroll
         for (int j = 0; j < FT_GROUP; j++) {
             const int r = rg + j;
-            if (j >= nstep || r < ORB_EDGE || r >= y_hi) continue;   // wave-uniform
+            if (j >= nstep || (!PACKED && (r < ORB_EDGE || r >= y_hi))) continue;   // wave-uniform (PACKED: the rows of the bands differ, see rowmask)
             const v2s e0 = pick2<3>(rgt[j], ctr[j]), e1 = pick2<1>(rgt[j], rgt[j]);     // (+3, 0)
             const v2s w0 = pick2<1>(ctr[j], lft[j]), w1 = pick2<3>(ctr[j], lft[j]);     // (-3, 0)
             const v2s a0 = pmax(pmin(ulo[j + 6], ulo[j]), pmin(e0, w0)), b0 = pmin(pmax(ulo[j + 6], ulo[j]), pmax(e0, w0));
@@ -361,7 +362,13 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
             acc1 |= (v2u(u1) >> j) & (0x80008000u >> j);
         }
         // one word: byte i = pixel i, bit 7-j of the byte = row j
-        const uint32_t verdict = __builtin_amdgcn_perm(acc1, acc0, 0x07050301u) & ok_mask;
+        uint32_t verdict = __builtin_amdgcn_perm(acc1, acc0, 0x07050301u) & ok_mask;
+        if (PACKED) {
+            // rows of this lane's band outside the detectable rows: step row j is level row rg + 32 * band + j
+            const int rl = rg + __mul24(band, FT_ROWS);
+            const int jlo = min(max(ORB_EDGE - rl, 0), 8), jhi = min(max(y_hi - rl, 0), 8);   // valid j in [jlo, jhi)
+            verdict &= (((0xFFu >> jlo) & ~(0xFFu >> jhi)) & 0xFFu) * 0x01010101u;
+        }
         // exact scores of the survivors (their rings lie in tile rows this wave has just written)
         // Only full batches of 128 are scored here; the remainder waits in the queue for the next step.
         if (__ballot(verdict != 0)) {
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
             const uint32_t code0 = ((uint32_t)grp << 11) | ((uint32_t)lane << 5);
             auto drain = [&](int n) {                          // n entries queued: score the full double batches
                 const int nfull = n & ~127;
-                for (int q = 0; q < nfull; q += 128) fast_score_queue2(queue + q, 128, lane, m0, s_img, min_th, s_map, s_list, &s_nlist);
+                for (int q = 0; q < nfull; q += 128) fast_score_queue2<PACKED>(queue + q, 128, lane, m0, s_img, min_th, s_map, s_list, &s_nlist, fb);
                 pending = n - nfull;
                 if (nfull) {                                   // move the remainder (< 128 entries) to the front
                     const uint16_t v0 = queue[nfull + lane], v1 = queue[min(nfull + 64 + lane, FT_QUEUE - 1)];
@@ -393,13 +400,12 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
             }
         }
     }
-    if (pending > 64) fast_score_queue2(queue, pending, lane, m0, s_img, min_th, s_map, s_list, &s_nlist);
-    else if (pending) fast_score_queue(queue, pending, lane, m0, s_img, min_th, s_map, s_list, &s_nlist);
+    if (pending > 64) fast_score_queue2<PACKED>(queue, pending, lane, m0, s_img, min_th, s_map, s_list, &s_nlist, fb);
+    else if (pending) fast_score_queue<PACKED>(queue, pending, lane, m0, s_img, min_th, s_map, s_list, &s_nlist, fb);
     __syncthreads();                                           // all scores of the tile are in the map
 
     // ---- non-maximum suppression inside the cell and emission
-    const int segi = (by * g.ntx + bx) * 4 + wv;
-    uint2* out = seg + (size_t)f * seg_per_frame + g.seg_off + (size_t)segi * FT_SEGCAP;
+    out += (size_t)(tile * 4 + wv) * FT_SEGCAP;
     int nout = 0;
     // One scored output pixel per lane: tile column xl, map row m. Neighbours in another cell (or
     // outside the detectable area, where the map is 0) do not count.
@@ -410,6 +416,10 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
             const uint8_t* c = &s_map[__mul24(m, FT_P) + xl];
             s = c[0];
             x = xs - 4 + xl; y = y0 - 1 + m;
+            if (PACKED) {
+                const int bb = (int)(__umul24((uint32_t)(xl >> 2), fb.magic) >> 16);   // the pixel's band
+                x -= __mul24(bb, 4 * fb.lpb); y += __mul24(bb, FT_ROWS);
+            }
             const int ux = x - ORB_EDGE, uy = y - ORB_EDGE;
             // position inside the cell: n / d == n * ceil(2^22 / d) >> 22 for n * d < 2^22 (full-rate multiplies)
             const int xin = ux - __mul24((int)(__umul24((uint32_t)ux, g.wcell_m22) >> 22), g.wcell);
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
         // map itself (a scored pixel is a non-zero byte) and compacts them through its queue
         const int mh = 1 + 8 * wv;
         uint32_t bits = 0;
-        if (lane >= 1 && lane <= 62) {                         // lanes 0 and 63 hold neighbour columns only
+        if (band_ok && li >= 1 && li < last_li) {              // halo lanes hold neighbour columns only
             // rows outside the detectable area were never scored: their bytes are zero
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -472,6 +482,56 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
     }
     if (lane == 0) {
         if (nout > FT_SEGCAP) { atomicOr(status, 1); nout = FT_SEGCAP; }
-        seg_count[(size_t)f * segc_per_frame + g.segc_off + segi] = nout;
+        out_count[tile * 4 + wv] = nout;
+    }
+}
+
+// Grid: one dimension, all plain (PACKED: all packed) tiles of all levels of all frames, level-major, then
+// frame, tile row, tile column: the large levels start first. Plain and packed tiles are separate
+// launches (one kernel holding both variants ran the plain one 7 % slower). Output: segment (tile, wave)
+// of FT_SEGCAP entries {x | y << 16 (relative to the detection window origin (16,16)), score} and its
+// entry count; the packed tiles of a level come behind its plain ones.
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, const PlanDev* __restrict__ plan, int frames,
+                                              uint2* __restrict__ seg, int* __restrict__ seg_count,
+                                              int* __restrict__ status, unsigned id_base, Level0View v0) {
+    __shared__ __align__(16) uint8_t s_map[FT_MAP_ROWS * FT_P];
+    __shared__ __align__(16) uint8_t s_img[FT_IMG_ROWS * FT_P];
+    __shared__ uint16_t s_queue[4][FT_QUEUE];
+    __shared__ uint16_t s_list[FT_LIST];                       // scored output pixels of the tile
+    __shared__ int s_nlist;
+    // which tile: everything here is uniform over the workgroup (scalar unit)
+    // The levels take consecutive ranges of the dispatch order; inside its level's range a workgroup
+    // is remapped so that neighbouring tiles (shared halo rows / lines) share an L2 and every level
+    // is spread over all XCDs (tiles of different levels do not cost the same).
+    const unsigned id = id_base + blockIdx.x;                  // a launch may cover a sub-range of the levels
+    const uint32_t* cum = plan->fast_cum[PACKED ? 1 : 0];
+    int level = 0;
+    while (level + 1 < plan->nlevels && id >= cum[level + 1] * (unsigned)frames) level++;
+    const LevelGeom g = plan->lv[level];
+    const int nplain = g.fast_ntx_plain * g.nty;
+    const int ntiles = PACKED ? g.fast_ntiles - nplain : nplain;   // of this kind, per frame
+    const unsigned rem = xcd_contiguous(id - cum[level] * (unsigned)frames, (unsigned)(ntiles * frames));
+    const unsigned mt = plan->fast_tiles_magic[PACKED ? 1 : 0][level], mx = plan->fast_ntx_magic[level];
+    const int f = (int)(mt ? __umulhi(rem, mt) : rem);
+    const int t = (int)(rem - (unsigned)f * (unsigned)ntiles);
+    // where the level's pixel (0, 0) of this frame is: in its plane, or (level 0 read in place) in the caller's image
+    const bool inplace = level == 0 && v0.org != nullptr;
+    const int pitch = inplace ? v0.pitch : g.pitch;
+    const uint8_t* org = inplace ? v0.org + (size_t)f * v0.frame_bytes
+                                 : pyr + g.pyr_off + (size_t)f * g.plane_bytes + (size_t)ORB_OY * g.pitch + ORB_OX;
+    const int xlimit = inplace ? v0.xlim : g.pitch - ORB_OX;
+    uint2* out = seg + (size_t)f * plan->seg_per_frame + g.seg_off;
+    int* out_count = seg_count + (size_t)f * plan->segc_per_frame + g.segc_off;
+    if (!PACKED) {
+        const int by = (int)(mx ? __umulhi((unsigned)t, mx) : (unsigned)t);
+        const int bx = t - by * g.fast_ntx_plain;
+        fast_tile<false>(g, org, pitch, xlimit, ORB_MINB + FT_COLS * bx, ORB_EDGE + FT_ROWS * by, t, FastBands{64, 1, 0u},
+                         plan->min_th, out, out_count, status, s_map, s_img, s_queue, s_list, &s_nlist);
+    } else {
+        const int first = t * g.fast_bands;                    // first tile row of this packed tile
+        const FastBands fb = {g.fast_lpb, min(g.fast_bands, g.nty - first), (65536u + (unsigned)g.fast_lpb - 1u) / (unsigned)g.fast_lpb};
+        fast_tile<true>(g, org, pitch, xlimit, ORB_MINB + FT_COLS * (g.ntx - 1), ORB_EDGE + FT_ROWS * first, nplain + t, fb,
+                        plan->min_th, out, out_count, status, s_map, s_img, s_queue, s_list, &s_nlist);
     }
 }

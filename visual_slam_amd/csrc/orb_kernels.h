@@ -606,7 +606,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
     // it found nothing at iniThFAST)
     const int ncells = g.ncols * g.nrows;
     for (int i = tid; i < (ncells + 31) / 32; i += QT_THREADS) cellbits[i] = 0;
-    const int nseg = g.ntx * g.nty * 4;
+    const int nseg = g.fast_ntiles * 4;
     uint32_t* segbase = smem;                      // [nseg + 1], aliases the node arrays (not in use yet)
     {
         // step 1: segment sizes -> exclusive prefix sums = positions in `keys`

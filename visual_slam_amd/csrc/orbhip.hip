@@ -112,6 +112,7 @@ struct orbhip_extractor {
     int plan_lanes = 0;            // workspaces allocated for the current plan
     int max_lanes = 1;             // ORBHIP_LANES=2..4: that many passes of a large batch in flight (a few % more throughput)
     hipEvent_t ev_fork = nullptr;
+    int fast_pack = 1;             // ORBHIP_FAST_PACK=0: every tile of k_fast is a plain one (no bands in the last tile column)
     int inplace_l0 = 1;            // ORBHIP_INPLACE_LEVEL0=0: always copy gray input into the level-0 plane
     std::vector<int> l1_base;      // per 4-pixel group of level 1's plane: 4-aligned first source column of its taps
     int overlap = 0;               // ORBHIP_OVERLAP=1: FAST of level 0 runs beside the resize chain on aux_stream
@@ -289,6 +290,7 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
             g.ncols = g.nrows = 0; g.wcell = g.hcell = 1;
             g.n_ini = 0; g.hx = 1.f; g.node_cap = 1; g.keys_cap = 1;
             g.ntx = g.nty = 0;
+            g.fast_ntiles = g.fast_ntx_plain = 0; g.fast_bands = 1; g.fast_lpb = 64;
         } else {
             g.wcell = (int)std::ceil(width / g.ncols);
             g.hcell = (int)std::ceil(height / g.nrows);
@@ -306,11 +308,20 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
             g.node_cap = std::max(e->per_level[l] + 3, 4 * g.n_ini) + 1;
             g.ntx = (g.w - ORB_EDGE - ORB_MINB + FT_COLS - 1) / FT_COLS;
             g.nty = (dh + FT_ROWS - 1) / FT_ROWS;
+            // the last tile column: lanes its output columns need plus two halo lanes; a wave holds 64 / that
+            // many bands (tile rows side by side). Level 0 stays plain: it may be read in place from an image
+            // that has no rows below it, and a band's loads are not clamped to the level.
+            const int rest = (g.w - ORB_EDGE - ORB_MINB) - FT_COLS * (g.ntx - 1);
+            g.fast_lpb = (rest + 3) / 4 + 2;
+            g.fast_bands = (l == 0 || e->fast_pack == 0) ? 1 : 64 / g.fast_lpb;
+            if (g.fast_bands < 2) { g.fast_bands = 1; g.fast_lpb = 64; }
+            g.fast_ntx_plain = g.fast_bands > 1 ? g.ntx - 1 : g.ntx;
+            g.fast_ntiles = g.fast_ntx_plain * g.nty + (g.fast_bands > 1 ? (g.nty + g.fast_bands - 1) / g.fast_bands : 0);
         }
-        g.seg_off = seg_off; seg_off += (size_t)g.ntx * g.nty * 4 * FT_SEGCAP;
-        g.segc_off = segc_off; segc_off += g.ntx * g.nty * 4;
+        g.seg_off = seg_off; seg_off += (size_t)g.fast_ntiles * 4 * FT_SEGCAP;
+        g.segc_off = segc_off; segc_off += g.fast_ntiles * 4;
         g.keys_off = keys_off; keys_off += g.keys_cap;
-        g.qt_words = std::max(20 * g.node_cap, g.ntx * g.nty * 4 + 1);
+        g.qt_words = std::max(20 * g.node_cap, g.fast_ntiles * 4 + 1);
         {
             // node arrays (20 words per node) plus the per-cell bit mask: in LDS when they fit, else in a global slice
             const size_t words = (size_t)g.qt_words + (size_t)(g.ncols * g.nrows + 31) / 32;
@@ -330,18 +341,21 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
         g.xtab_off = tab_off; tab_off += (ORB_OX + g.w + ORB_EDGE + 3) / 4 * 4;
         g.ytab_off = tab_off; tab_off += (g.rows + 1) & ~1;
     }
-    P.fast_cum[0] = 0;
+    P.fast_cum[0][0] = P.fast_cum[1][0] = 0;
     for (int l = 0; l < nl; l++) {
-        const unsigned tiles = (unsigned)(P.lv[l].ntx * P.lv[l].nty);
-        P.fast_cum[l + 1] = P.fast_cum[l] + tiles;
-        P.fast_tiles_magic[l] = grid_magic(tiles);
-        P.fast_ntx_magic[l] = grid_magic((unsigned)P.lv[l].ntx);
+        const unsigned plain = (unsigned)(P.lv[l].fast_ntx_plain * P.lv[l].nty), packed = (unsigned)P.lv[l].fast_ntiles - plain;
+        P.fast_cum[0][l + 1] = P.fast_cum[0][l] + plain;
+        P.fast_cum[1][l + 1] = P.fast_cum[1][l] + packed;
+        P.fast_tiles_magic[0][l] = grid_magic(plain);
+        P.fast_tiles_magic[1][l] = grid_magic(packed);
+        P.fast_ntx_magic[l] = grid_magic((unsigned)P.lv[l].fast_ntx_plain);
         // the magic divisions in k_fast are exact for n * d < 2^32
+        const unsigned tiles = std::max(plain, packed);
         if ((unsigned long long)tiles * frames * std::max(tiles, 1u) >= (1ull << 32)) {
             e->err = "too many FAST tiles per pass"; return ORBHIP_ERR_GEOMETRY;
         }
     }
-    if ((unsigned long long)P.fast_cum[nl] * frames >= (1ull << 31)) { e->err = "too many FAST tiles per pass"; return ORBHIP_ERR_GEOMETRY; }
+    if ((unsigned long long)(P.fast_cum[0][nl] + P.fast_cum[1][nl]) * frames >= (1ull << 31)) { e->err = "too many FAST tiles per pass"; return ORBHIP_ERR_GEOMETRY; }
     P.seg_per_frame = std::max(seg_off, (size_t)1);
     P.segc_per_frame = std::max(segc_off, 1);
     P.keys_per_frame = keys_off;
@@ -484,13 +498,13 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
     }
     // FAST is bound by vector issue, the resize chain by memory: with `overlap` level 0's FAST runs on
     // a second stream beside the chain and the remaining levels follow on the main stream
-    const unsigned split = (e->overlap && nl > 1) ? P.fast_cum[1] * (unsigned)frames : 0u;
+    const unsigned split = (e->overlap && nl > 1) ? P.fast_cum[0][1] * (unsigned)frames : 0u;
     if (split) {
         HIP_TRY(e, hipEventRecord(e->ev_l0, s));
         HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->ev_l0, 0));
         {
             SpanGuard t(e, e->aux_stream, KC_FAST);
-            hipLaunchKernelGGL(k_fast, dim3(split), dim3(256), 0, e->aux_stream,
+            hipLaunchKernelGGL(k_fast<false>, dim3(split), dim3(256), 0, e->aux_stream,
                                W.d_pyr, e->d_plan, frames, W.d_seg, W.d_seg_count, e->d_status, 0u, W.v0);
         }
         HIP_TRY(e, hipEventRecord(e->ev_f0, e->aux_stream));
@@ -521,10 +535,14 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
             hipLaunchKernelGGL((k_resize<false, false>), grid, blk2, 0, s, W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g,
                                e->d_tabs, c4_end, 0, 0);
     }
-    if (P.fast_cum[nl] * (unsigned)frames > split) {           // all (remaining) levels in one launch
+    {                                                          // all (remaining) levels in one launch per kind of tile
         SpanGuard t(e, s, KC_FAST);
-        hipLaunchKernelGGL(k_fast, dim3(P.fast_cum[nl] * (unsigned)frames - split), dim3(256), 0, s,
-                           W.d_pyr, e->d_plan, frames, W.d_seg, W.d_seg_count, e->d_status, split, W.v0);
+        if (P.fast_cum[0][nl] * (unsigned)frames > split)
+            hipLaunchKernelGGL(k_fast<false>, dim3(P.fast_cum[0][nl] * (unsigned)frames - split), dim3(256), 0, s,
+                               W.d_pyr, e->d_plan, frames, W.d_seg, W.d_seg_count, e->d_status, split, W.v0);
+        if (P.fast_cum[1][nl])
+            hipLaunchKernelGGL(k_fast<true>, dim3(P.fast_cum[1][nl] * (unsigned)frames), dim3(256), 0, s,
+                               W.d_pyr, e->d_plan, frames, W.d_seg, W.d_seg_count, e->d_status, 0u, W.v0);
     }
     if (split) HIP_TRY(e, hipStreamWaitEvent(s, e->ev_f0, 0));
     {
@@ -647,6 +665,7 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
     if (const char* v = std::getenv("ORBHIP_LANES")) e->max_lanes = std::min(kLanes, std::max(1, std::atoi(v)));
     if (const char* v = std::getenv("ORBHIP_OVERLAP")) e->overlap = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_INPLACE_LEVEL0")) e->inplace_l0 = std::atoi(v) != 0;
+    if (const char* v = std::getenv("ORBHIP_FAST_PACK")) e->fast_pack = std::atoi(v) != 0;
     *out = e;
     return ORBHIP_OK;
 }
