@@ -381,21 +381,9 @@ __device__ __forceinline__ void resize_rows(const uint8_t* __restrict__ src, uin
 #pragma unroll
     for (int k = 0; k < RS_RPT; k++) {
         // consecutive output rows usually share a source row: the upper row of k is the lower row of k-1
-#ifdef RS_EXP_NOLOAD
-        va[k].a = lbase * 3 + k; va[k].b = lbase ^ ty[k].s0; va[k].c = lbase + 77 * ty[k].s1;
-        vb[k].a = lbase * 5 + k; vb[k].b = lbase ^ ty[k].s1; vb[k].c = lbase + 31 * ty[k].s0;
-#elif defined(RS_EXP_DWORD)
-        if (k == 0 || ty[k].s0 != ty[k - 1].s1) {
-            va[k].a = *reinterpret_cast<const uint32_t*>(S + ((uint32_t)((int)ty[k].s0 * gs.pitch) + lbase));
-            va[k].b = va[k].a * 3; va[k].c = va[k].a + 5;
-        }
-        vb[k].a = *reinterpret_cast<const uint32_t*>(S + ((uint32_t)((int)ty[k].s1 * gs.pitch) + lbase));
-        vb[k].b = vb[k].a * 7; vb[k].c = vb[k].a + 9;
-#else
         if (k == 0 || ty[k].s0 != ty[k - 1].s1)
             va[k] = *reinterpret_cast<const Row12*>(S + ((uint32_t)((int)ty[k].s0 * gs.pitch) + lbase));
         vb[k] = *reinterpret_cast<const Row12*>(S + ((uint32_t)((int)ty[k].s1 * gs.pitch) + lbase));
-#endif
     }
     auto hpass = [&](const Row12& v, uint32_t (&h)[4]) {
         // CLAMP: whole dwords first (the bytes wanted start in dword sh / 4 of the window)
@@ -447,10 +435,7 @@ __device__ __forceinline__ void resize_rows(const uint8_t* __restrict__ src, uin
         const v2us two = {2, 2};
         const uint32_t q01 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(v2us, pair[0]) >> two);
         const uint32_t q23 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(v2us, pair[1]) >> two);
-        uint32_t out = __builtin_amdgcn_perm(q23, q01, 0x06040200u);
-#ifdef RS_EXP_NOALU
-        out = vb[k].a ^ vb[k].b ^ vb[k].c ^ ((k == 0 || ty[k].s0 != ty[k - 1].s1) ? va[k].a : 0u);
-#endif
+        const uint32_t out = __builtin_amdgcn_perm(q23, q01, 0x06040200u);
         *reinterpret_cast<uint32_t*>(D + ((uint32_t)(r * gd.pitch) + 4u * (uint32_t)c4)) = out;
     }
 }
@@ -530,7 +515,10 @@ __device__ __forceinline__ int qt_quadrant(uint32_t bx, uint32_t by, int x, int 
 // Runs `body(e, k0)` over all keys of a thread (key k0 + u * QT_THREADS in e[u]; slots past the
 // end hold a dead key at the window origin), QT_KU keys per trip. The keys of the next trip are
 // requested before the body runs: the loops over keys are bound by memory latency.
-#define QT_KU 8
+#ifndef QT_KU
+#define QT_KU 4   // (8 keys per trip need 104 registers per lane; 4 need 68, and the workgroups that fit beside each other
+                  // hide more latency than the longer trips did: VGA-sized frames 30 % faster, 1080p unchanged)
+#endif
 template <typename F>
 __device__ __forceinline__ void qt_for_keys(const uint2* keys, int nkeys, int tid, F&& body) {
     const uint2 dead = make_uint2(3u | (3u << 16), ORB_DEAD_LABEL << 10);
@@ -1176,10 +1164,18 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     const float ang_rad = angle * factorPI;
     float a, b;                                   // cosf(ang_rad), sinf(ang_rad)
     sincos_rounded(ang_rad, &a, &b);
-    const int wv4 = g.w & ~3;
     const int ties_even = plan->blur_ties_even;
-    const v2f_t ab = {a, b}, ba = {b, a};
+    const v2f_t ab = {a, b}, nba = {-b, a};
     const uint16_t* hp_top = hp + 19 * DS_HP_P + 19;          // row sums of (row offset -3, column offset 0) from the keypoint
+    // cvRound without conversions: adding 1.5 * 2^23 to a float of small magnitude rounds it to the nearest
+    // integer, ties to even, and leaves 0x4B400000 + that integer in the bits of the sum. The two biased
+    // integers go into the address as they are (the 24-bit multiply sees 0x400000 + ry); the biases are
+    // taken off once, as a constant.
+    const float round_magic = 12582912.0f;
+    const int magic_bits = 0x4B400000;
+    const int index_bias = 0x400000 * DS_HP_P + magic_bits;
+    // the legacy column kernel rounds an exact half to even for x < (w & ~3): kx + rx below that limit
+    const int tie_limit = ties_even ? (g.w & ~3) - kx + magic_bits : magic_bits - 0x10000;
     unsigned long long bits[4];
 #pragma unroll
     for (int rnd = 0; rnd < 4; rnd++) {
@@ -1192,18 +1188,25 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
             const float py = (float)(signed char)(pk >> (16 * e + 8));
             // (rx, ry) = round(px * a - py * b, px * b + py * a): two packed multiplies, each product
             // rounded on its own as in the scalar expression
-            const v2f_t pxv = v2f_t{px, px} * ab, pyv = v2f_t{py, py} * ba;
-            const int rx = (int)rintf(pxv.x - pyv.x);
-            const int ry = (int)rintf(pxv.y + pyv.y);
+            // (px * a - py * b as px * a + py * (-b): the same products and the same sum)
+            const v2f_t pxv = v2f_t{px, px} * ab, pyv = v2f_t{py, py} * nba;
+            const v2f_t rr = (pxv + pyv) + v2f_t{round_magic, round_magic};
+            const int irx = __float_as_int(rr.x), iry = __float_as_int(rr.y);
             // taps < 2^6, row sums < 2^17: full-rate 24-bit multiplies are exact. h = the top tap (row
-            // ry - 3), so that all seven reads have non-negative constant offsets.
-            const uint16_t* h = hp_top + (__mul24(ry, DS_HP_P) + rx);
-            const int acc = __mul24(t0, h[3 * DS_HP_P]) + __mul24(t1, h[2 * DS_HP_P] + h[4 * DS_HP_P]) +
-                            __mul24(t2, h[DS_HP_P] + h[5 * DS_HP_P]) + __mul24(t3, h[0] + h[6 * DS_HP_P]);
-            // round half up; the legacy column kernel rounds an exact half to even for x < (w & ~3)
-            uint32_t qv = (uint32_t)(acc + 0x8000) >> 16;
-            const bool tie_even = (acc & 0xFFFF) == 0x8000 && ties_even && (kx + rx) < wv4;
-            qv = tie_even ? (qv & ~1u) : qv;
+            // ry - 3), so that all seven reads have non-negative constant offsets (the index is made
+            // opaque to the compiler, which would otherwise spread the large bias over the seven reads).
+            int hidx = __mul24(iry, DS_HP_P) + irx - index_bias;
+            asm("" : "+v"(hidx));
+            const uint16_t* h = hp_top + hidx;
+            // the sum with the rounding half already in it
+            int m = __mul24(t0, h[3 * DS_HP_P]) + 0x8000;
+            m += __mul24(t1, h[2 * DS_HP_P] + h[4 * DS_HP_P]);
+            m += __mul24(t2, h[DS_HP_P] + h[5 * DS_HP_P]);
+            m += __mul24(t3, h[0] + h[6 * DS_HP_P]);
+            // round half up: m >> 16; an exact half (low 16 bits of m zero) that came out odd goes down to the
+            // even value where the legacy rule applies
+            const bool tie_odd = ((uint32_t)m & 0x1FFFFu) == 0x10000u && irx < tie_limit;
+            const uint32_t qv = ((uint32_t)m >> 16) - (uint32_t)tie_odd;
             val[e] = (int)min(qv, 255u);
         }
         bits[rnd] = __ballot(val[0] < val[1]);
