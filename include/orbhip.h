@@ -391,7 +391,7 @@ int orbhip_search_by_projection_sim3(orbhip_extractor* e, const float* world, co
  * "GetMapPointMatches()[i] exists and is not bad". Frame: d_kp_f = mvKeys (angle), descriptors, node
  * ids. nnratio = mfNNratio, check_orientation = mbCheckOrientation. d_match_f[f][i2] = index of the
  * key-frame feature whose map point vpMapPointMatches[i2] receives, -1 = NULL; d_nmatches[f] = the
- * returned count. At most 4096 keypoint slots per frame (the node grouping is sorted on chip). */
+ * returned count. Frames of up to 4096 keypoint slots are sorted on chip, larger ones (up to 65535) in a slice of global memory. */
 int orbhip_search_by_bow_batch_device(orbhip_extractor* e, int nframes, int cap, const orbhip_keypoint* d_kp_kf,
                                       const uint8_t* d_desc_kf, const uint32_t* d_node_kf, const uint8_t* d_flags_kf,
                                       const int* d_cnt_kf, const orbhip_keypoint* d_kp_f, const uint8_t* d_desc_f,

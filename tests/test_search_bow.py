@@ -97,16 +97,31 @@ def test_hip_search_by_bow_edge_cases():
     assert gn == 0 and np.all(gm == -1)
     gm, gn = orbhip.SearchByBoW(ex, s["k1"][:0], s["d1"][:0], s["n1"][:0], s["flags"][:0], s["k2"], s["d2"], s["n2"])
     assert gn == 0 and np.all(gm == -1)
-    # sizes around the padding of the on-chip sort, and the capacity refusal
+    # sizes around the padding of the on-chip sort
     for n in (63, 64, 65, 1023, 1025):
         cut = dict(s, k1=s["k1"][:n], d1=s["d1"][:n], n1=s["n1"][:n], flags=s["flags"][:n])
         om, on = run_oracle(cut, 0.8, True)
         gm, gn = orbhip.SearchByBoW(ex, cut["k1"], cut["d1"], cut["n1"], cut["flags"], cut["k2"], cut["d2"], cut["n2"], 0.8, True)
         assert gn == on and np.array_equal(gm, om), n
-    with pytest.raises(orbhip.OrbHipError):
-        big = np.zeros(5000, orbhip.KP_DTYPE)
-        orbhip.SearchByBoW(ex, big, np.zeros((5000, 32), np.uint8), np.zeros(5000, np.uint32), np.ones(5000, np.uint8),
-                           s["k2"], s["d2"], s["n2"])
+
+
+@pytest.mark.gpu
+def test_hip_search_by_bow_large_frames_in_global_memory():
+    """Frames with more than 4096 features (the 8000-feature configuration): the sort arrays move to global memory;
+    both forms of the function, results identical to the oracle's."""
+    from oracle import orb_oracle as O
+    from visual_slam_amd import orbhip
+    prm = (8000, 1.2, 8, 20, 7)
+    s = scenario(1920, 1080, 99, 5, -2, nnodes=400, prm=prm)
+    assert len(s["k1"]) > 4096 and len(s["k2"]) > 4096
+    ex = orbhip.ORBextractor(*prm)
+    om, on = run_oracle(s, 0.7, True)
+    gm, gn = orbhip.SearchByBoW(ex, s["k1"], s["d1"], s["n1"], s["flags"], s["k2"], s["d2"], s["n2"], 0.7, True)
+    assert on > 1000 and gn == on and np.array_equal(gm, om)
+    f2 = (np.random.default_rng(3).random(len(s["k2"])) < 0.7).astype(np.uint8)
+    om, on = O.search_by_bow_keyframes(s["k1"], s["d1"], s["n1"], s["flags"], s["k2"], s["d2"], s["n2"], f2, 0.75, True)
+    gm, gn = orbhip.SearchByBoWKeyFrames(ex, s["k1"], s["d1"], s["n1"], s["flags"], s["k2"], s["d2"], s["n2"], f2, 0.75, True)
+    assert on > 500 and gn == on and np.array_equal(gm, om)
 
 
 # ---- SearchByBoW(pKF1, pKF2, vpMatches12) (reference src/ORBmatcher.cc:519-652)

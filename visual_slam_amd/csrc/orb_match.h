@@ -1027,20 +1027,27 @@ __device__ __forceinline__ void mb_sort(unsigned long long* a, int n) {
 // src/ORBmatcher.cc:519-652, loop detection): side 2 is a key frame too, only its features with a
 // good map point (flags2) are candidates, the acceptance test is bestDist1 < TH_LOW, and the result
 // is indexed by the feature of side 1 (match[i1] = feature of side 2).
-template <bool KFKF>
+//
+// SPILL: frames with more than 4096 features keep the sort arrays in a slice of global memory per pair
+// (26 bytes per padded slot) instead of LDS; the code is the same, the workgroup's barriers order its own
+// global accesses. Feature indices travel in 16 bits of the sort keys: at most 65535 features per frame.
+template <bool KFKF, bool SPILL = false>
 __global__ __launch_bounds__(MP_THREADS) void k_search_bow(const GridKp* __restrict__ kp1, const uint8_t* __restrict__ desc1,
                                                            const uint32_t* __restrict__ node1, const uint8_t* __restrict__ flags1,
                                                            const int* __restrict__ cnt1, const GridKp* __restrict__ kp2,
                                                            const uint8_t* __restrict__ desc2, const uint32_t* __restrict__ node2,
                                                            const uint8_t* __restrict__ flags2,
                                                            const int* __restrict__ cnt2, int cap, int npad, float nnratio,
-                                                           int check_orientation, int* __restrict__ match2, int* __restrict__ nmatches_out) {
+                                                           int check_orientation, int* __restrict__ match2, int* __restrict__ nmatches_out,
+                                                           uint8_t* __restrict__ spill = nullptr, size_t spill_stride = 0) {
     extern __shared__ __align__(16) uint8_t mb_smem[];
-    unsigned long long* A = reinterpret_cast<unsigned long long*>(mb_smem);   // key frame: node << 16 | index, sorted
+    uint8_t* const smem = SPILL ? spill + (size_t)blockIdx.x * spill_stride : mb_smem;
+    unsigned long long* A = reinterpret_cast<unsigned long long*>(smem);      // key frame: node << 16 | index, sorted
     unsigned long long* B = A + npad;                                          // frame: the same
     uint32_t* run_start = reinterpret_cast<uint32_t*>(B + npad);              // scan of the run heads, then first position of every run
     uint8_t* taken2 = reinterpret_cast<uint8_t*>(run_start + npad);           // frame feature already holds a match (KFKF: or has no good map point)
     uint8_t* bin2 = taken2 + npad;                                            // rotation bin of the match of the output slot, 0xFF = none
+    uint32_t* runs = SPILL ? reinterpret_cast<uint32_t*>(bin2 + npad) : run_start;   // first position of every run (LDS: in place of the flags)
     __shared__ uint32_t s_tmp[MP_WAVES];
     __shared__ int s_hist[MT_HISTO];
     __shared__ int s_count[2];                                                // matches made, matches removed
@@ -1068,12 +1075,16 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_bow(const GridKp* __restr
         run_start[i] = (nd != MB_NONE_NODE && (i == 0 || (uint32_t)(A[i - 1] >> 16) != nd)) ? 1u : 0u;
     }
     __syncthreads();
-    uint32_t mine[4];                                          // npad <= 4096: at most 4 positions per thread
+    uint32_t mine[4];                                          // LDS: npad <= 4096, at most 4 positions per thread
     const int per = npad / MP_THREADS > 0 ? npad / MP_THREADS : 1;
     // exclusive scan over consecutive chunks (thread t owns positions t*per .. t*per+per-1)
     uint32_t s = 0;
+    if (SPILL) {
+        for (int k = 0; k < per; k++) s += run_start[tid * per + k];
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const int i = tid * per + k; mine[k] = (k < per && i < npad) ? run_start[i] : 0u; s += mine[k]; }
+        for (int k = 0; k < 4; k++) { const int i = tid * per + k; mine[k] = (k < per && i < npad) ? run_start[i] : 0u; s += mine[k]; }
+    }
     const uint32_t inc = wave_scan_incl(s);
     if (lane == 63) s_tmp[wv] = inc;
     __syncthreads();
@@ -1082,16 +1093,23 @@ __global__ __launch_bounds__(MP_THREADS) void k_search_bow(const GridKp* __restr
     for (int w = 0; w < MP_WAVES; w++) { if (w < wv) off += s_tmp[w]; nruns += s_tmp[w]; }
     uint32_t run = off + inc - s;
     __syncthreads();                                           // every thread has read its flags: the array is reused for the run starts
+    if (SPILL) {
+        for (int k = 0; k < per; k++) {                        // (a separate array: the flags are read again here)
+            const int i = tid * per + k;
+            if (run_start[i]) { runs[run] = (uint32_t)i; run++; }
+        }
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int i = tid * per + k;
-        if (mine[k]) { run_start[run] = (uint32_t)i; run++; }
+        for (int k = 0; k < 4; k++) {
+            const int i = tid * per + k;
+            if (mine[k]) { run_start[run] = (uint32_t)i; run++; }
+        }
     }
     __syncthreads();
 
     int made = 0;
     for (uint32_t r = wv; r < nruns; r += MP_WAVES) {
-        const int start = (int)run_start[r];
+        const int start = (int)runs[r];
         const uint32_t nd = (uint32_t)(A[start] >> 16);
         // the frame's features of this node: B[fs .. fe)
         int lo = 0, hi = npad;                                 // lower bound of nd << 16

@@ -1844,22 +1844,36 @@ static int search_by_bow_launch(orbhip_extractor* e, bool kfkf, int nframes, int
     if (!e || nframes < 1 || cap < 1 || !d_kp1 || !d_desc1 || !d_node1 || !d_flags1 || !d_cnt1 || !d_kp2 || !d_desc2 ||
         !d_node2 || !d_cnt2 || !d_match || !d_nmatches || (kfkf && !d_flags2))
         return ORBHIP_ERR_ARG;
-    if (cap > 4096) { e->err = "too many keypoints per frame for the on-chip sort of the bag-of-words matcher"; return ORBHIP_ERR_CAPACITY; }
+    if (cap > 65535) { e->err = "the bag-of-words matcher indexes features with 16 bits (cap <= 65535)"; return ORBHIP_ERR_CAPACITY; }
     int npad = 64;
     while (npad < cap) npad <<= 1;
-    const size_t lds = (size_t)MB_LDS_PER_SLOT * npad;
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
-    const void* fn = kfkf ? reinterpret_cast<const void*>(k_search_bow<true>) : reinterpret_cast<const void*>(k_search_bow<false>);
+    const GridKp* k1 = reinterpret_cast<const GridKp*>(d_kp1);
+    const GridKp* k2 = reinterpret_cast<const GridKp*>(d_kp2);
+    if (npad > 4096) {
+        // the sort arrays of such frames live in global memory (the same kernel, 26 bytes per padded slot and pair)
+        const size_t stride = ((size_t)(MB_LDS_PER_SLOT + 4) * npad + 255) / 256 * 256;
+        int rc = match_spill(e, stride * (size_t)nframes);
+        if (rc) return rc;
+        if (kfkf)
+            hipLaunchKernelGGL((k_search_bow<true, true>), dim3(nframes), dim3(MP_THREADS), 0, s, k1, d_desc1, d_node1, d_flags1, d_cnt1, k2, d_desc2,
+                               d_node2, d_flags2, d_cnt2, cap, npad, nnratio, check_orientation, d_match, d_nmatches, e->d_match_spill, stride);
+        else
+            hipLaunchKernelGGL((k_search_bow<false, true>), dim3(nframes), dim3(MP_THREADS), 0, s, k1, d_desc1, d_node1, d_flags1, d_cnt1, k2, d_desc2,
+                               d_node2, d_flags2, d_cnt2, cap, npad, nnratio, check_orientation, d_match, d_nmatches, e->d_match_spill, stride);
+        HIP_TRY(e, hipGetLastError());
+        return ORBHIP_OK;
+    }
+    const size_t lds = (size_t)MB_LDS_PER_SLOT * npad;
+    const void* fn = kfkf ? reinterpret_cast<const void*>(k_search_bow<true, false>) : reinterpret_cast<const void*>(k_search_bow<false, false>);
     if (lds > 40 * 1024) HIP_TRY(e, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (kfkf)
-        hipLaunchKernelGGL(k_search_bow<true>, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const GridKp*>(d_kp1), d_desc1,
-                           d_node1, d_flags1, d_cnt1, reinterpret_cast<const GridKp*>(d_kp2), d_desc2, d_node2, d_flags2, d_cnt2, cap, npad,
-                           nnratio, check_orientation, d_match, d_nmatches);
+        hipLaunchKernelGGL((k_search_bow<true, false>), dim3(nframes), dim3(MP_THREADS), lds, s, k1, d_desc1, d_node1, d_flags1, d_cnt1, k2, d_desc2,
+                           d_node2, d_flags2, d_cnt2, cap, npad, nnratio, check_orientation, d_match, d_nmatches, static_cast<uint8_t*>(nullptr), (size_t)0);
     else
-        hipLaunchKernelGGL(k_search_bow<false>, dim3(nframes), dim3(MP_THREADS), lds, s, reinterpret_cast<const GridKp*>(d_kp1), d_desc1,
-                           d_node1, d_flags1, d_cnt1, reinterpret_cast<const GridKp*>(d_kp2), d_desc2, d_node2, d_flags2, d_cnt2, cap, npad,
-                           nnratio, check_orientation, d_match, d_nmatches);
+        hipLaunchKernelGGL((k_search_bow<false, false>), dim3(nframes), dim3(MP_THREADS), lds, s, k1, d_desc1, d_node1, d_flags1, d_cnt1, k2, d_desc2,
+                           d_node2, d_flags2, d_cnt2, cap, npad, nnratio, check_orientation, d_match, d_nmatches, static_cast<uint8_t*>(nullptr), (size_t)0);
     HIP_TRY(e, hipGetLastError());
     return ORBHIP_OK;
 }
