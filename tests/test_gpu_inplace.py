@@ -21,17 +21,18 @@ from visual_slam_amd import synth
 PRM = (1000, 1.2, 8, 20, 7)
 
 
-def _extractor(inplace, prm=PRM):
+def _extractor(inplace, prm=PRM, var="ORBHIP_INPLACE_LEVEL0"):
+    """A handle created with the switch `var` on or off (the library reads it in orbhip_create)."""
     from visual_slam_amd import orbhip
-    old = os.environ.get("ORBHIP_INPLACE_LEVEL0")
-    os.environ["ORBHIP_INPLACE_LEVEL0"] = "1" if inplace else "0"
+    old = os.environ.get(var)
+    os.environ[var] = "1" if inplace else "0"
     try:
         return orbhip.ORBextractor(*prm)
     finally:
         if old is None:
-            del os.environ["ORBHIP_INPLACE_LEVEL0"]
+            del os.environ[var]
         else:
-            os.environ["ORBHIP_INPLACE_LEVEL0"] = old
+            os.environ[var] = old
 
 
 def _run_device(g, frames, pad=0, offset=0):
@@ -130,3 +131,20 @@ def test_stereo_refinement_reads_level0_in_place():
     assert np.array_equal(c0, c1) and np.array_equal(m0, m1) and m0.min() > 50
     for i in range(n):
         assert np.array_equal(u0[i].view(np.uint32), u1[i].view(np.uint32)) and np.array_equal(d0[i].view(np.uint32), d1[i].view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,kind", [(640, 480, "noise"), (752, 480, "blocks"), (1920, 1080, "blocks"), (500, 300, "noise"), (290, 240, "lowc")])
+def test_packed_fast_tiles_equal_plain_tiles(w, h, kind):
+    """The narrow last tile column of a level as several tile rows side by side in a wave (the default) against one
+    workgroup per tile (ORBHIP_FAST_PACK=0): the same candidates level by level, the same output."""
+    frame = synth.frame(kind, w, h, 21)
+    g_pk, g_pl = _extractor(True, var="ORBHIP_FAST_PACK"), _extractor(False, var="ORBHIP_FAST_PACK")
+    kp_pk, d_pk = g_pk(frame, fetch_pyramid=False)
+    cand_pk = [g_pk.debug_candidates(l) for l in range(PRM[2])]
+    kp_pl, d_pl = g_pl(frame, fetch_pyramid=False)
+    cand_pl = [g_pl.debug_candidates(l) for l in range(PRM[2])]
+    assert len(kp_pk) > 100
+    for l in range(PRM[2]):
+        assert np.array_equal(cand_pk[l], cand_pl[l]), l
+    assert np.array_equal(kp_pk, kp_pl) and np.array_equal(d_pk, d_pl)
