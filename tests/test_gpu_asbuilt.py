@@ -6,7 +6,7 @@ orders nodes of equal size by heap address (src/ORBextractor.cc:591,684). The de
 expressions and orders equal sizes by creation sequence. These tests run the device against the oracle in its
 fused mode and in its heap-address mode, hold the north-star bar (>= 99.9 % of descriptors bit-exact) against
 the fused oracle, attribute every differing descriptor to a rounding flip of a rotated sample coordinate, and
-write the counts to gpurun_out/asbuilt_report.json (quoted in DESIGN.md).
+write the counts to gpurun_out/asbuilt_report.json.
 
 The oracle itself is pinned by analytic known answers only (the reference holds no vectors): parity unpinned.
 """
