@@ -1035,9 +1035,10 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     const int pitch = inplace ? v0.pitch : g.pitch;
     const uint8_t* P = inplace ? v0.org + (size_t)f * v0.frame_bytes
                                : pyr + g.pyr_off + (size_t)f * g.plane_bytes + (size_t)ORB_OY * g.pitch + ORB_OX;
-    // ---- stage rows ky-22..ky+22, 13 aligned dwords per row starting at or before column kx-22
+    // ---- stage rows ky-22..ky+22, 13 dwords per row starting at column kx-22 (byte-aligned loads: staged
+    // byte c of a row is column kx-22+c, whatever the alignment of that column in memory)
     const int col0 = kx - 22;                     // >= -3: keypoints are >= 19 px from the level edge
-    const int colA = col0 & ~3, off = col0 & 3;   // (a plane has 32 border columns left of x = 0 and 19 rows above y = 0)
+                                                  // (a plane has 32 border columns left of x = 0 and 19 rows above y = 0)
     uint8_t* raw = s_raw[wv];
     // disc weights of this lane's row for the orientation step below (loaded early)
     const uint4* dwp = reinterpret_cast<const uint4*>(plan->disc_w[lane < 31 ? (lane < 15 ? 15 - lane : lane - 15) : 0]);
@@ -1051,7 +1052,7 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     // src/ORBextractor.cc:1086) the missing rows and columns are rebuilt by reflection. Wave-uniform
     // branches; the columns beyond kx+-22 of a staged row are never used.
     const bool edge = !(kx >= 22 && kx + 22 <= g.w - 1 && ky >= 21 && ky + 22 <= g.h - 1);
-    if (inplace && (edge || colA + 52 > v0.xlim)) {
+    if (inplace && (edge || col0 + 52 > v0.xlim)) {
         // an image read in place has nothing readable around it: byte by byte, reflecting the coordinates
         if (sc < 13) {
 #pragma unroll 1
@@ -1063,7 +1064,7 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
                 uint32_t v = 0;
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
-                    int x = colA + 4 * sc + b;
+                    int x = col0 + 4 * sc + b;
                     x = x < 0 ? -x : x >= g.w ? 2 * (g.w - 1) - x : x;
                     v |= (uint32_t)P[y * pitch + x] << (8 * b);
                 }
@@ -1071,12 +1072,13 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
             }
         }
     } else {
-        int goff = (ky - 22 + sr) * pitch + colA + sc * 4;     // a frame is far below 2 GB
+        int goff = (ky - 22 + sr) * pitch + col0 + sc * 4;     // a frame is far below 2 GB
         if (sc < 13) {
 #pragma unroll
             for (int p = 0; p < 11; p++) {
                 if (4 * p + sr < 45) {
-                    const uint32_t v = *reinterpret_cast<const uint32_t*>(P + goff);
+                    uint32_t v;
+                    __builtin_memcpy(&v, P + goff, 4);         // one dword load at any byte alignment
                     *reinterpret_cast<uint32_t*>(dst + p * 4 * DS_RAW_P) = v;
                 }
                 goff += 4 * pitch;
@@ -1100,8 +1102,8 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
                 const int jj = (t >= 88) ? 2 : (t >= 44) ? 1 : 0;
                 uint8_t* row = raw + (1 + t - 44 * jj) * DS_RAW_P;
                 const int xl = -1 - jj, xr = g.w + jj;         // columns left / right of the level
-                if (xl >= colA) row[xl - colA] = row[-xl - colA];
-                if (xr - colA < DS_RAW_P) row[xr - colA] = row[2 * (g.w - 1) - xr - colA];
+                if (xl >= col0) row[xl - col0] = row[-xl - col0];
+                if (xr - col0 < DS_RAW_P) row[xr - col0] = row[2 * (g.w - 1) - xr - col0];
             }
         }
     }
@@ -1111,7 +1113,7 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     if (lane < 31) {
         // lane = row v of the disc: 32 bytes from u = -15 on, two byte dot products per dword
         // (sum of I and sum of (u + 15) * I over |u| <= umax[|v|])
-        const int first = off + 7;                // byte of u = -15 in the staged row
+        const int first = 7;                      // byte of u = -15 in the staged row
         const uint32_t* rw = reinterpret_cast<const uint32_t*>(&raw[(lane + 7) * DS_RAW_P]) + (first >> 2);
         const uint32_t sh = first & 3;
         uint32_t d[9];
@@ -1133,11 +1135,16 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     m01 = __builtin_amdgcn_readlane((int)wave_scan_incl((uint32_t)m01), 63);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     // ---- horizontal blur pass: hp[r][c] for rows ky-22..ky+22, columns kx-19..kx+19. A lane
-    // produces 4 adjacent sums from 16 staged bytes with byte-aligned dword extracts and
-    // v_dot4_u32_u8 against the taps packed as bytes.
+    // produces 4 adjacent sums from 12 staged bytes (3 dwords) with v_dot4_u32_u8: the seven taps of sum q
+    // lie at bytes q .. q+6, so every sum is two or three byte dot products of the same three dwords
+    // against the taps shifted to where they belong (ten constant patterns; no byte shifting of the data).
     const int t0 = plan->blur_taps[0], t1 = plan->blur_taps[1], t2 = plan->blur_taps[2], t3 = plan->blur_taps[3];
-    const uint32_t tap_lo = (uint32_t)t3 | ((uint32_t)t2 << 8) | ((uint32_t)t1 << 16) | ((uint32_t)t0 << 24);
-    const uint32_t tap_hi = (uint32_t)t1 | ((uint32_t)t2 << 8) | ((uint32_t)t3 << 16);
+    const uint32_t T[7] = {(uint32_t)t3, (uint32_t)t2, (uint32_t)t1, (uint32_t)t0, (uint32_t)t1, (uint32_t)t2, (uint32_t)t3};
+    auto pat = [&](int k0) -> uint32_t {              // bytes = taps k0 .. k0+3 (zero outside 0..6)
+        uint32_t v = 0;
+        for (int i = 0; i < 4; i++) if (k0 + i >= 0 && k0 + i < 7) v |= T[k0 + i] << (8 * i);
+        return v;
+    };
     uint16_t* hp = s_hp[wv];
     // (only the items a rotated test point can need: see PlanDev::hp_items)
     uint32_t items[ORB_HP_ITEMS / 64];
@@ -1147,15 +1154,15 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     for (int k = 0; k < ORB_HP_ITEMS / 64; k++) {
         // sums c..c+3 of row r (column 39 is padding): the item holds both byte offsets
         const uint32_t* rw = reinterpret_cast<const uint32_t*>(raw + (items[k] & 0xFFFF));
-        const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2], d3 = rw[3];
-        const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, off), e1 = __builtin_amdgcn_alignbyte(d2, d1, off),
-                       e2 = __builtin_amdgcn_alignbyte(d3, d2, off);          // bytes off+c .. off+c+11
+        const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2];
         uint32_t acc[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const uint32_t lo = q ? __builtin_amdgcn_alignbyte(e1, e0, q) : e0;   // taps at c+q .. c+q+3
-            const uint32_t hi = q ? __builtin_amdgcn_alignbyte(e2, e1, q) : e1;   // taps at c+q+4 .. c+q+6
-            acc[q] = __builtin_amdgcn_udot4(lo, tap_lo, __builtin_amdgcn_udot4(hi, tap_hi, 0u, false), false);
+            // sum q: bytes q+k of the twelve times tap k: dword j holds the taps 4j-q .. 4j-q+3
+            uint32_t a = __builtin_amdgcn_udot4(d0, pat(-q), 0u, false);
+            a = __builtin_amdgcn_udot4(d1, pat(4 - q), a, false);
+            if (q >= 2) a = __builtin_amdgcn_udot4(d2, pat(8 - q), a, false);
+            acc[q] = a;
         }
         *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(hp) + (items[k] >> 16)) = make_uint2(acc[0] | (acc[1] << 16), acc[2] | (acc[3] << 16));
     }
