@@ -112,6 +112,7 @@ struct orbhip_extractor {
     int plan_lanes = 0;            // workspaces allocated for the current plan
     int max_lanes = 1;             // ORBHIP_LANES=2..4: that many passes of a large batch in flight (a few % more throughput)
     hipEvent_t ev_fork = nullptr;
+    size_t qt_lds_limit = 160 * 1024 - 256;   // node arrays of a level beyond this many bytes live in global memory (ORBHIP_QT_LDS_LIMIT)
     int fast_pack = 1;             // ORBHIP_FAST_PACK=0: every tile of k_fast is a plain one (no bands in the last tile column)
     int inplace_l0 = 1;            // ORBHIP_INPLACE_LEVEL0=0: always copy gray input into the level-0 plane
     std::vector<int> l1_base;      // per 4-pixel group of level 1's plane: 4-aligned first source column of its taps
@@ -325,7 +326,7 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
         {
             // node arrays (20 words per node) plus the per-cell bit mask: in LDS when they fit, else in a global slice
             const size_t words = (size_t)g.qt_words + (size_t)(g.ncols * g.nrows + 31) / 32;
-            if (words * 4 > 160 * 1024 - 256) {
+            if (words * 4 > e->qt_lds_limit) {
                 P.qt_spill_slot[l] = P.qt_nspill++;
                 spill_words = std::max(spill_words, (words + 63) / 64 * 64);
             } else {
@@ -666,6 +667,7 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
     if (const char* v = std::getenv("ORBHIP_OVERLAP")) e->overlap = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_INPLACE_LEVEL0")) e->inplace_l0 = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_FAST_PACK")) e->fast_pack = std::atoi(v) != 0;
+    if (const char* v = std::getenv("ORBHIP_QT_LDS_LIMIT")) e->qt_lds_limit = std::min<size_t>(160 * 1024 - 256, (size_t)std::max(std::atoi(v), 1024));
     *out = e;
     return ORBHIP_OK;
 }
