@@ -68,7 +68,10 @@ int orbhip_destroy(orbhip_extractor* e);
  * for one 8-bit gray host image. `kp` (capacity `cap` records) and `desc` (cap x 32 bytes) are
  * host buffers; *n receives the keypoint count. The mask argument of the reference is ignored
  * there (include/ORBextractor.h:58) and has no counterpart here. An empty image returns
- * ORBHIP_ERR_EMPTY and leaves the outputs untouched. */
+ * ORBHIP_ERR_EMPTY and leaves the outputs untouched. From the second call with the same image size
+ * and capacity on, the copy up, the kernel launches and the copies down are replayed as one captured
+ * HIP graph (the call is launch-bound at camera-frame sizes); ORBHIP_GRAPH=0 in the environment, read
+ * by orbhip_create, keeps the plain launches. */
 int orbhip_extract(orbhip_extractor* e, const uint8_t* img, int width, int height, size_t stride,
                    orbhip_keypoint* kp, int cap, int* n, uint8_t* desc);
 

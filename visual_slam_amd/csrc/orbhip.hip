@@ -136,6 +136,14 @@ struct orbhip_extractor {
     size_t h_pyr_bytes = 0;
     unsigned long long h_pyr_gen = 0;
     int h_pyr_frame = -1;
+    // The single-frame host call (what a SLAM front end makes per camera frame) is launch-bound: its copy up,
+    // its kernel launches and its copies down are captured into a HIP graph the second time a configuration
+    // is seen and replayed from then on (ORBHIP_GRAPH=0: never). config_gen counts everything that
+    // invalidates the captured pointers: a new plan, new staging buffers, new rectification maps.
+    int use_graph = 1;
+    hipGraphExec_t graph_exec = nullptr;
+    struct GraphKey { int w, h, channels, rgb, cap; unsigned long long gen; } graph_key = {0, 0, 0, 0, 0, 0}, graph_seen = {0, 0, 0, 0, 0, 0};
+    unsigned long long config_gen = 1;
     // staging for the host entry points
     uint8_t* d_in = nullptr; size_t d_in_bytes = 0;
     uint8_t* h_in = nullptr; size_t h_in_bytes = 0;      // pinned: rows are packed here, then one copy up
@@ -173,6 +181,7 @@ void dfree(T*& p) {
 }
 
 void free_plan(orbhip_extractor* e) {
+    e->config_gen++;
     dfree(e->d_plan); dfree(e->d_tabs);
     for (Workspace& w : e->ws) {
         dfree(w.d_pyr); dfree(w.d_seg); dfree(w.d_seg_count);
@@ -667,6 +676,7 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
     if (const char* v = std::getenv("ORBHIP_OVERLAP")) e->overlap = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_INPLACE_LEVEL0")) e->inplace_l0 = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_FAST_PACK")) e->fast_pack = std::atoi(v) != 0;
+    if (const char* v = std::getenv("ORBHIP_GRAPH")) e->use_graph = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_QT_LDS_LIMIT")) e->qt_lds_limit = std::min<size_t>(160 * 1024 - 256, (size_t)std::max(std::atoi(v), 1024));
     *out = e;
     return ORBHIP_OK;
@@ -678,6 +688,7 @@ int orbhip_destroy(orbhip_extractor* e) {
     (void)hipDeviceSynchronize();
     collect_timing(e);
     for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
+    if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
     free_plan(e);
     dfree(e->d_status); dfree(e->d_in); dfree(e->d_out_kp); dfree(e->d_out_desc); dfree(e->d_out_cnt);
     dfree(e->d_st_sad); dfree(e->d_st_rinfo); dfree(e->d_st_bins); dfree(e->d_st_tmp); dfree(e->d_match_spill);
@@ -809,8 +820,10 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
         dfree(e->d_in);
         HIP_TRY(e, hipMalloc(&e->d_in, need));
         e->d_in_bytes = need;
+        e->config_gen++;
     }
     if (need > e->h_in_bytes) {
+        e->config_gen++;
         if (e->h_in) (void)hipHostFree(e->h_in);
         e->h_in = nullptr; e->h_in_bytes = 0;
         HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_in), need, hipHostMallocDefault));
@@ -818,6 +831,7 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
     }
     if ((size_t)nframes > e->d_out_frames || cap != e->d_out_cap) {
         HIP_TRY(e, hipDeviceSynchronize());
+        e->config_gen++;
         dfree(e->d_out_kp); dfree(e->d_out_desc); dfree(e->d_out_cnt);
         HIP_TRY(e, hipMalloc(&e->d_out_kp, (size_t)nframes * cap * sizeof(orbhip_keypoint)));
         HIP_TRY(e, hipMalloc(&e->d_out_desc, (size_t)nframes * cap * 32));
@@ -827,6 +841,7 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
     const size_t kp_bytes = (size_t)nframes * cap * sizeof(orbhip_keypoint), desc_bytes = (size_t)nframes * cap * 32;
     const size_t cnt_bytes = ((size_t)nframes * sizeof(int) + 15) & ~(size_t)15;
     if (kp_bytes + desc_bytes + cnt_bytes > e->h_out_bytes) {
+        e->config_gen++;
         if (e->h_out) (void)hipHostFree(e->h_out);
         e->h_out = nullptr; e->h_out_bytes = 0;
         HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_out), kp_bytes + desc_bytes + cnt_bytes, hipHostMallocDefault));
@@ -840,15 +855,62 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
         if (row_stride == dev_row) std::memcpy(dst, src, (size_t)(height - 1) * row_stride + (size_t)width * channels);
         else for (int y = 0; y < height; y++) std::memcpy(dst + (size_t)y * dev_row, src + (size_t)y * row_stride, (size_t)width * channels);
     }
-    HIP_TRY(e, hipMemcpyAsync(e->d_in, e->h_in, need, hipMemcpyHostToDevice, e->stream));
-    // (the staging buffer's rows are dev_row bytes long, all of them the library's own)
-    int rc = extract_device_impl(e, e->d_in, nframes, width, height, dev_row, dev_frame, dev_row, channels, rgb,
-                                 reinterpret_cast<orbhip_keypoint*>(e->d_out_kp), e->d_out_desc, e->d_out_cnt, cap, nullptr);
-    if (rc) return rc;
     uint8_t* h_cnt = e->h_out, *h_kp = e->h_out + cnt_bytes, *h_desc = h_kp + kp_bytes;
-    HIP_TRY(e, hipMemcpyAsync(h_cnt, e->d_out_cnt, (size_t)nframes * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipMemcpyAsync(h_kp, e->d_out_kp, kp_bytes, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipMemcpyAsync(h_desc, e->d_out_desc, desc_bytes, hipMemcpyDeviceToHost, e->stream));
+    int rc = ORBHIP_OK;
+    // One frame through a plan that exists: replay the captured graph, or capture it when this configuration
+    // comes a second time (the first call of a configuration builds plan and buffers and runs the plain way).
+    const orbhip_extractor::GraphKey key = {width, height, channels, rgb, cap, e->config_gen};
+    auto same = [](const orbhip_extractor::GraphKey& a, const orbhip_extractor::GraphKey& b) {
+        return a.w == b.w && a.h == b.h && a.channels == b.channels && a.rgb == b.rgb && a.cap == b.cap && a.gen == b.gen;
+    };
+    const bool graphable = e->use_graph && nframes == 1 && !e->timing && !e->overlap && e->plan_w == width && e->plan_h == height &&
+                           e->plan_frames >= 1 && e->plan_lanes >= 1 &&
+                           !(e->d_map_x && (channels != 1 || width != e->map_w || height != e->map_h || width < 2 || height < 2));
+    bool replayed = false;
+    if (graphable && !(e->graph_exec && same(key, e->graph_key)) && same(key, e->graph_seen)) {
+        if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        HIP_TRY(e, hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+        hipError_t st = hipMemcpyAsync(e->d_in, e->h_in, need, hipMemcpyHostToDevice, e->stream);
+        int prc = st == hipSuccess ? run_pass(e, e->ws[0], e->stream, e->d_in, 1, dev_row, dev_frame, dev_row, channels, rgb, e->d_out_kp,
+                                              e->d_out_desc, e->d_out_cnt, cap, 0) : ORBHIP_ERR_HIP;
+        if (prc == ORBHIP_OK) {
+            st = hipMemcpyAsync(h_cnt, e->d_out_cnt, sizeof(int), hipMemcpyDeviceToHost, e->stream);
+            if (st == hipSuccess) st = hipMemcpyAsync(h_kp, e->d_out_kp, kp_bytes, hipMemcpyDeviceToHost, e->stream);
+            if (st == hipSuccess) st = hipMemcpyAsync(h_desc, e->d_out_desc, desc_bytes, hipMemcpyDeviceToHost, e->stream);
+        }
+        const hipError_t end = hipStreamEndCapture(e->stream, &graph);   // always: the stream must leave capture mode
+        if (prc == ORBHIP_OK && st == hipSuccess && end == hipSuccess && graph &&
+            hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess)
+            e->graph_key = key;
+        else
+            e->graph_exec = nullptr;                               // no graph for this configuration: the plain way below
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+    }
+    if (graphable && e->graph_exec && same(key, e->graph_key)) {
+        if (e->last_stream && e->last_stream != e->stream) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_busy, 0));
+        e->last_stream = e->stream;
+        HIP_TRY(e, hipGraphLaunch(e->graph_exec, e->stream));
+        HIP_TRY(e, hipEventRecord(e->ev_busy, e->stream));
+        // what run_pass notes on the host for a pass
+        Workspace& W = e->ws[0];
+        W.l0_in_plane = W.v0.org == nullptr;
+        e->last_pass_frames = 1; e->last_ws = 0; e->pass_gen++;
+        replayed = true;
+    }
+    e->graph_seen = key;
+    if (!replayed) {
+        HIP_TRY(e, hipMemcpyAsync(e->d_in, e->h_in, need, hipMemcpyHostToDevice, e->stream));
+        // (the staging buffer's rows are dev_row bytes long, all of them the library's own)
+        rc = extract_device_impl(e, e->d_in, nframes, width, height, dev_row, dev_frame, dev_row, channels, rgb,
+                                 reinterpret_cast<orbhip_keypoint*>(e->d_out_kp), e->d_out_desc, e->d_out_cnt, cap, nullptr);
+        if (rc) return rc;
+        HIP_TRY(e, hipMemcpyAsync(h_cnt, e->d_out_cnt, (size_t)nframes * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(h_kp, e->d_out_kp, kp_bytes, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(h_desc, e->d_out_desc, desc_bytes, hipMemcpyDeviceToHost, e->stream));
+    }
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     collect_timing(e);
     rc = check_status(e);
@@ -1478,6 +1540,7 @@ int orbhip_set_rectification(orbhip_extractor* e, const float* map_x, const floa
     if (!e) return ORBHIP_ERR_ARG;
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipDeviceSynchronize());                        // no pass may still read the old maps
+    e->config_gen++;                                           // a captured graph holds the old maps (or none)
     dfree(e->d_map_x); dfree(e->d_map_y);
     e->map_w = e->map_h = 0;
     if (!map_x && !map_y) return ORBHIP_OK;
