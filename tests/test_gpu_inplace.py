@@ -148,3 +148,21 @@ def test_packed_fast_tiles_equal_plain_tiles(w, h, kind):
     for l in range(PRM[2]):
         assert np.array_equal(cand_pk[l], cand_pl[l]), l
     assert np.array_equal(kp_pk, kp_pl) and np.array_equal(d_pk, d_pl)
+
+
+@pytest.mark.gpu
+def test_device_batch_in_several_passes_reads_every_frame_in_place():
+    """A device-resident batch larger than a pass (max_batch = 3, 8 frames): every pass reads its own frames of the
+    caller's buffer as level 0; each frame's output equals the single-frame result."""
+    from visual_slam_amd import orbhip
+    w, h, n = 752, 480, 8
+    frames = np.stack([synth.frame("noise" if i == 5 else "blocks", w, h, 30 + i) for i in range(n)])
+    g = orbhip.ORBextractor(*PRM, max_batch=3)
+    res, keep = _run_device(g, frames)
+    single = orbhip.ORBextractor(*PRM)
+    for i in range(n):
+        kp, desc = single(frames[i], fetch_pyramid=False)
+        gk = res[i][0]
+        assert len(gk) == len(kp) and len(kp) > 100, i
+        assert np.array_equal(gk[:, 0], kp["x"]) and np.array_equal(gk[:, 1], kp["y"]) and np.array_equal(gk[:, 3], kp["angle"]), i
+        assert np.array_equal(res[i][1], desc), i
