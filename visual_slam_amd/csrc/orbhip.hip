@@ -868,11 +868,11 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
                            !(e->d_map_x && (channels != 1 || width != e->map_w || height != e->map_h || width < 2 || height < 2));
     bool replayed = false;
     if (graphable && !(e->graph_exec && same(key, e->graph_key)) && same(key, e->graph_seen)) {
-        if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
         hipGraph_t graph = nullptr;
         HIP_TRY(e, hipStreamSynchronize(e->stream));
-        HIP_TRY(e, hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-        hipError_t st = hipMemcpyAsync(e->d_in, e->h_in, need, hipMemcpyHostToDevice, e->stream);
+        if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+        hipError_t st = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
+        if (st == hipSuccess) st = hipMemcpyAsync(e->d_in, e->h_in, need, hipMemcpyHostToDevice, e->stream);
         int prc = st == hipSuccess ? run_pass(e, e->ws[0], e->stream, e->d_in, 1, dev_row, dev_frame, dev_row, channels, rgb, e->d_out_kp,
                                               e->d_out_desc, e->d_out_cnt, cap, 0) : ORBHIP_ERR_HIP;
         if (prc == ORBHIP_OK) {
@@ -884,8 +884,10 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
         if (prc == ORBHIP_OK && st == hipSuccess && end == hipSuccess && graph &&
             hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess)
             e->graph_key = key;
-        else
-            e->graph_exec = nullptr;                               // no graph for this configuration: the plain way below
+        else {
+            e->graph_exec = nullptr;                               // capture is not available here: plain launches from now on
+            e->use_graph = 0;
+        }
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
     }
