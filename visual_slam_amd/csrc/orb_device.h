@@ -19,7 +19,6 @@
 #define ORB_MINB 16           // minBorderX/Y = EDGE_THRESHOLD-3 (src/ORBextractor.cc:773)
 #define ORB_MAX_LEVELS 16
 #define ORB_HP_ITEMS 384      // 6 trips of a wave
-#define ORB_DEAD_LABEL 0x3FFFFFu   // candidate dropped by the per-cell threshold rule (22-bit label field)
 
 struct RsTab {                // one bilinear tap pair of cv::resize (8 bytes)
     uint16_t s0, s1;          // source indices (already clamped)

@@ -512,36 +512,46 @@ __device__ __forceinline__ int qt_quadrant(uint32_t bx, uint32_t by, int x, int 
     return (x < mx ? 0 : 1) | (y < my ? 0 : 2);
 }
 
-// Runs `body(e, k0)` over all keys of a thread (key k0 + u * QT_THREADS in e[u]; slots past the
-// end hold a dead key at the window origin), QT_KU keys per trip. The keys of the next trip are
-// requested before the body runs: the loops over keys are bound by memory latency.
+// The keys of a (frame, level) are three arrays: position x | y << 16 and FAST score, written once when the
+// survivors are gathered, and the label word (quadrant | list node << 2, all ones = dropped) that every round
+// of the distribution rewrites: 16 bits while the node arrays fit LDS (fewer than 2048 nodes), 32 bits for the
+// levels that keep them in global memory. A round then moves 8 bytes per key (position read, label read
+// and written), which is what bounds the kernel on large frames.
+//
+// Runs `body(a, b, k0)` over all keys of a thread (key k0 + u * QT_THREADS: its position in a[u], its
+// entry of the second array - label or score - in b[u]; slots past the end hold a dropped key at the
+// window origin), QT_KU keys per trip. The keys of the next trip are requested before the body runs:
+// the loops over keys are bound by memory latency.
 #ifndef QT_KU
 #define QT_KU 4   // (8 keys per trip need 104 registers per lane; 4 need 68, and the workgroups that fit beside each other
                   // hide more latency than the longer trips did: VGA-sized frames 30 % faster, 1080p unchanged)
 #endif
-template <typename F>
-__device__ __forceinline__ void qt_for_keys(const uint2* keys, int nkeys, int tid, F&& body) {
-    const uint2 dead = make_uint2(3u | (3u << 16), ORB_DEAD_LABEL << 10);
-    uint2 e[QT_KU];
+template <typename S, typename F>
+__device__ __forceinline__ void qt_for_keys(const uint32_t* xy, const S* second, uint32_t second_dead, int nkeys, int tid, F&& body) {
+    const uint32_t xy_dead = 3u | (3u << 16);
+    uint32_t a[QT_KU], b[QT_KU];
 #pragma unroll
     for (int u = 0; u < QT_KU; u++) {
         const int k = tid + u * QT_THREADS;
-        e[u] = dead;
-        if (k < nkeys) e[u] = keys[k];
+        a[u] = xy_dead; b[u] = second_dead;
+        if (k < nkeys) { a[u] = xy[k]; b[u] = second[k]; }
     }
     for (int k0 = tid; k0 < nkeys; k0 += QT_KU * QT_THREADS) {
-        uint2 nx[QT_KU];
+        uint32_t na[QT_KU], nb[QT_KU];
 #pragma unroll
         for (int u = 0; u < QT_KU; u++) {
             const int k = k0 + (QT_KU + u) * QT_THREADS;
-            nx[u] = dead;
-            if (k < nkeys) nx[u] = keys[k];
+            na[u] = xy_dead; nb[u] = second_dead;
+            if (k < nkeys) { na[u] = xy[k]; nb[u] = second[k]; }
         }
-        body(e, k0);
+        body(a, b, k0);
 #pragma unroll
-        for (int u = 0; u < QT_KU; u++) e[u] = nx[u];
+        for (int u = 0; u < QT_KU; u++) { a[u] = na[u]; b[u] = nb[u]; }
     }
 }
+
+template <bool WIDE> struct QtLabel { typedef uint16_t type; };
+template <> struct QtLabel<true> { typedef uint32_t type; };
 
 // SPILL = false: the node arrays live in LDS (every level whose quota fits: 80 bytes per list node).
 // SPILL = true: the levels whose node arrays do not fit (quotas beyond ~2000 features on one level; the
@@ -552,7 +562,8 @@ template <bool SPILL>
 __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restrict__ plan,
                                                          const uint2* __restrict__ seg,
                                                          const int* __restrict__ seg_count,
-                                                         uint2* __restrict__ keys_all,
+                                                         uint32_t* __restrict__ keys_xy_all, uint8_t* __restrict__ keys_score_all,
+                                                         uint32_t* __restrict__ keys_label_all,
                                                          int* __restrict__ key_count,
                                                          LevelKp* __restrict__ lvl_kp,
                                                          int* __restrict__ lvl_cnt,
@@ -585,10 +596,15 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         q.cbase = p; p += M;
     }
     uint32_t* cellbits = smem + g.qt_words;        // one bit per FAST cell: it has a survivor >= iniTh
-    uint2* keys = keys_all + (size_t)f * plan->keys_per_frame + g.keys_off;
+    typedef typename QtLabel<SPILL>::type Lab;                 // label word: quadrant | node << 2
+    const uint32_t lab_dead = (uint32_t)(Lab)~(Lab)0;
+    const size_t kbase = (size_t)f * plan->keys_per_frame + g.keys_off;
+    uint32_t* kxy = keys_xy_all + kbase;
+    uint8_t* ksc = keys_score_all + kbase;
+    Lab* klab = reinterpret_cast<Lab*>(keys_label_all + kbase);   // (a 32-bit slot per key either way)
     const int ini_th = plan->ini_th;
 
-    // ---- gather the FAST survivors of this level from the (tile, wave) segments into `keys`
+    // ---- gather the FAST survivors of this level from the (tile, wave) segments into the key arrays
     // (any order: everything below is order-independent) and mark the cells that have a survivor
     // at the initial threshold (src/ORBextractor.cc:808-816: a cell is re-run at minThFAST only when
     // it found nothing at iniThFAST)
@@ -631,7 +647,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
             for (int u = 0; u < QT_KU; u++) {
                 const int p = p0 + u * QT_THREADS;
                 if (p >= ncopy) continue;
-                keys[p] = e[u];
+                kxy[p] = e[u].x;
+                ksc[p] = (uint8_t)e[u].y;
                 if ((int)(e[u].y & 0xFF) >= ini_th) {
                     const int x = e[u].x & 0xFFFF, y = e[u].x >> 16;
                     const int c = __mul24((int)(__umul24((uint32_t)(y - 3), g.hcell_m22) >> 22), g.ncols) +
@@ -659,12 +676,12 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         q.cc[0][4 * i] = q.cc[0][4 * i + 1] = q.cc[0][4 * i + 2] = q.cc[0][4 * i + 3] = 0;
     }
     __syncthreads();
-    qt_for_keys(keys, nkeys, tid, [&](const uint2 (&e)[QT_KU], int k0) __attribute__((always_inline)) {
+    qt_for_keys(kxy, ksc, 0u, nkeys, tid, [&](const uint32_t (&exy)[QT_KU], const uint32_t (&esc)[QT_KU], int k0) __attribute__((always_inline)) {
         int x[QT_KU], y[QT_KU], s[QT_KU], cell[QT_KU], root[QT_KU];
         uint32_t cb[QT_KU], b0[QT_KU], b1[QT_KU];
 #pragma unroll
         for (int u = 0; u < QT_KU; u++) {
-            x[u] = e[u].x & 0xFFFF; y[u] = e[u].x >> 16; s[u] = e[u].y & 0xFF;
+            x[u] = exy[u] & 0xFFFF; y[u] = exy[u] >> 16; s[u] = (int)esc[u];
             cell[u] = __mul24((int)(__umul24((uint32_t)(y[u] - 3), g.hcell_m22) >> 22), g.ncols) + (int)(__umul24((uint32_t)(x[u] - 3), g.wcell_m22) >> 22);
             cb[u] = cellbits[cell[u] >> 5];
             root[u] = min(max((int)__fdiv_rn((float)x[u], g.hx), 0), L - 1);
@@ -674,13 +691,13 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         for (int u = 0; u < QT_KU; u++) {
             const int k = k0 + u * QT_THREADS;
             if (k >= nkeys) continue;
-            uint32_t lab = ORB_DEAD_LABEL, qd = 0;
+            uint32_t lab = lab_dead;
             if (s[u] >= ini_th || ((cb[u] >> (cell[u] & 31)) & 1) == 0) {
-                qd = qt_quadrant(b0[u], b1[u], x[u], y[u]);
+                const uint32_t qd = qt_quadrant(b0[u], b1[u], x[u], y[u]);
                 atomicAdd(&q.cc[0][4 * root[u] + qd], 1u);
-                lab = root[u];
+                lab = qd | ((uint32_t)root[u] << 2);
             }
-            keys[k].y = (uint32_t)s[u] | (qd << 8) | (lab << 10);
+            klab[k] = (Lab)lab;
         }
     });
     __syncthreads();
@@ -821,20 +838,19 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         else if (mode == 1 && Lnew + 3 * to_expand > N) mode = 2;
         // ---- E. keys follow their nodes
         if (!done) {
-            qt_for_keys(keys, nkeys, tid, [&](const uint2 (&e)[QT_KU], int k0) __attribute__((always_inline)) {
+            qt_for_keys(kxy, klab, lab_dead, nkeys, tid, [&](const uint32_t (&exy)[QT_KU], const uint32_t (&elab)[QT_KU], int k0) __attribute__((always_inline)) {
                 uint32_t li[QT_KU], nl[QT_KU], bx[QT_KU], by[QT_KU];
                 int ko[QT_KU];
                 bool alive[QT_KU];
 #pragma unroll
                 for (int u = 0; u < QT_KU; u++) {
-                    const uint32_t lab = e[u].y >> 10;
-                    alive[u] = lab != ORB_DEAD_LABEL;
-                    li[u] = alive[u] ? lab : 0u;
+                    alive[u] = elab[u] != lab_dead;
+                    li[u] = alive[u] ? elab[u] >> 2 : 0u;
                     ko[u] = q.kord[li[u]];
                 }
 #pragma unroll
                 for (int u = 0; u < QT_KU; u++) {
-                    const uint32_t qd = (e[u].y >> 8) & 3;
+                    const uint32_t qd = elab[u] & 3;
                     nl[u] = *(ko[u] >= 0 ? &cc_cur[4 * li[u] + qd] : &q.surv[li[u]]);
                     if (!alive[u]) nl[u] = 0;
                 }
@@ -843,42 +859,42 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
 #pragma unroll
                 for (int u = 0; u < QT_KU; u++) {
                     if (!alive[u]) continue;
-                    const uint32_t nq = qt_quadrant(bx[u], by[u], e[u].x & 0xFFFF, e[u].x >> 16);
+                    const uint32_t nq = qt_quadrant(bx[u], by[u], exy[u] & 0xFFFF, exy[u] >> 16);
                     atomicAdd(&cc_nxt[4 * nl[u] + nq], 1u);
-                    keys[k0 + u * QT_THREADS].y = (e[u].y & 0xFF) | (nq << 8) | (nl[u] << 10);
+                    klab[k0 + u * QT_THREADS] = (Lab)(nq | (nl[u] << 2));
                 }
             });
         } else {
             // ---- best response per node, first in candidate order on ties (src/ORBextractor.cc:744-760)
             for (int i = tid; i < Lnew; i += QT_THREADS) q.key64[i] = 0ull;
             __syncthreads();
-            qt_for_keys(keys, nkeys, tid, [&](const uint2 (&e)[QT_KU], int) __attribute__((always_inline)) {
-                uint32_t li[QT_KU], nl[QT_KU];
+            qt_for_keys(kxy, klab, lab_dead, nkeys, tid, [&](const uint32_t (&exy)[QT_KU], const uint32_t (&elab)[QT_KU], int k0) __attribute__((always_inline)) {
+                uint32_t li[QT_KU], nl[QT_KU], sc[QT_KU];
                 int ko[QT_KU];
                 bool alive[QT_KU];
 #pragma unroll
                 for (int u = 0; u < QT_KU; u++) {
-                    const uint32_t lab = e[u].y >> 10;
-                    alive[u] = lab != ORB_DEAD_LABEL;
-                    li[u] = alive[u] ? lab : 0u;
+                    alive[u] = elab[u] != lab_dead;            // (the slots past the end are dropped keys)
+                    li[u] = alive[u] ? elab[u] >> 2 : 0u;
                     ko[u] = q.kord[li[u]];
+                    sc[u] = alive[u] ? (uint32_t)ksc[k0 + u * QT_THREADS] : 0u;
                 }
 #pragma unroll
                 for (int u = 0; u < QT_KU; u++) {
-                    const uint32_t qd = (e[u].y >> 8) & 3;
+                    const uint32_t qd = elab[u] & 3;
                     nl[u] = *(ko[u] >= 0 ? &cc_cur[4 * li[u] + qd] : &q.surv[li[u]]);
                 }
 #pragma unroll
                 for (int u = 0; u < QT_KU; u++) {
                     if (!alive[u]) continue;
-                    const int x = e[u].x & 0xFFFF, y = e[u].x >> 16;
+                    const int x = exy[u] & 0xFFFF, y = exy[u] >> 16;
                     const int cx = (int)(__umul24((uint32_t)(x - 3), g.wcell_m22) >> 22);
                     const int cy = (int)(__umul24((uint32_t)(y - 3), g.hcell_m22) >> 22);
                     // (every factor stays below 2^24 and every product below 2^32: full-rate 24-bit multiplies)
                     const uint32_t row_in_cells = __umul24((uint32_t)(__mul24(cy, g.ncols) + cx), (uint32_t)g.hcell) +
                                                   (uint32_t)(y - 3 - __mul24(cy, g.hcell));
                     const uint32_t ord = __umul24(row_in_cells, (uint32_t)g.wcell) + (uint32_t)(x - 3 - __mul24(cx, g.wcell));
-                    atomicMax(&q.key64[nl[u]], ((unsigned long long)(e[u].y & 0xFF) << 32) | (0xFFFFFFFFu - ord));
+                    atomicMax(&q.key64[nl[u]], ((unsigned long long)sc[u] << 32) | (0xFFFFFFFFu - ord));
                 }
             });
         }

@@ -42,7 +42,10 @@ struct Workspace {
     uint8_t* d_pyr = nullptr;
     uint2* d_seg = nullptr;        // [frames][seg_per_frame]   FAST output segments
     int* d_seg_count = nullptr;    // [frames][segc_per_frame]
-    uint2* d_keys = nullptr;       // [frames][keys_per_frame]  compact keys of the quadtree
+    // keys of the quadtree, [frames][keys_per_frame] each: position x | y << 16, FAST score, label word
+    uint32_t* d_keys_xy = nullptr;
+    uint8_t* d_keys_score = nullptr;
+    uint32_t* d_keys_label = nullptr;   // (16 bits of every slot in use where a level's node arrays fit LDS)
     int* d_key_count = nullptr;    // [frames][nlevels]
     LevelKp* d_lvl_kp = nullptr;   // [frames][kp_per_frame]
     int* d_lvl_cnt = nullptr;      // [frames][nlevels]
@@ -185,7 +188,7 @@ void free_plan(orbhip_extractor* e) {
     dfree(e->d_plan); dfree(e->d_tabs);
     for (Workspace& w : e->ws) {
         dfree(w.d_pyr); dfree(w.d_seg); dfree(w.d_seg_count);
-        dfree(w.d_keys); dfree(w.d_key_count); dfree(w.d_lvl_kp); dfree(w.d_lvl_cnt); dfree(w.d_qt_spill);
+        dfree(w.d_keys_xy); dfree(w.d_keys_score); dfree(w.d_keys_label); dfree(w.d_key_count); dfree(w.d_lvl_kp); dfree(w.d_lvl_cnt); dfree(w.d_qt_spill);
     }
     e->plan_w = e->plan_h = e->plan_frames = e->plan_lanes = 0;
 }
@@ -408,7 +411,9 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
         HIP_TRY(e, hipMalloc(&W.d_pyr, pyr_off + 64));
         HIP_TRY(e, hipMalloc(&W.d_seg, (size_t)P.seg_per_frame * frames * sizeof(uint2)));
         HIP_TRY(e, hipMalloc(&W.d_seg_count, (size_t)P.segc_per_frame * frames * sizeof(int)));
-        HIP_TRY(e, hipMalloc(&W.d_keys, (size_t)P.keys_per_frame * frames * sizeof(uint2)));
+        HIP_TRY(e, hipMalloc(&W.d_keys_xy, (size_t)P.keys_per_frame * frames * sizeof(uint32_t)));
+        HIP_TRY(e, hipMalloc(&W.d_keys_score, (size_t)P.keys_per_frame * frames));
+        HIP_TRY(e, hipMalloc(&W.d_keys_label, (size_t)P.keys_per_frame * frames * sizeof(uint32_t)));
         HIP_TRY(e, hipMalloc(&W.d_key_count, (size_t)frames * nl * sizeof(int)));
         HIP_TRY(e, hipMalloc(&W.d_lvl_kp, (size_t)frames * P.kp_per_frame * sizeof(LevelKp)));
         HIP_TRY(e, hipMalloc(&W.d_lvl_cnt, (size_t)frames * nl * sizeof(int)));
@@ -559,11 +564,11 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
         SpanGuard t(e, s, KC_QUADTREE);
         if (P.qt_nspill < nl)
             hipLaunchKernelGGL(k_quadtree<false>, dim3(frames, nl), dim3(QT_THREADS), e->qt_lds, s,
-                               e->d_plan, W.d_seg, W.d_seg_count, W.d_keys, W.d_key_count, W.d_lvl_kp, W.d_lvl_cnt,
+                               e->d_plan, W.d_seg, W.d_seg_count, W.d_keys_xy, W.d_keys_score, W.d_keys_label, W.d_key_count, W.d_lvl_kp, W.d_lvl_cnt,
                                e->d_status, static_cast<uint32_t*>(nullptr), 0ull);
         if (P.qt_nspill)
             hipLaunchKernelGGL(k_quadtree<true>, dim3(frames, nl), dim3(QT_THREADS), 0, s,
-                               e->d_plan, W.d_seg, W.d_seg_count, W.d_keys, W.d_key_count, W.d_lvl_kp, W.d_lvl_cnt,
+                               e->d_plan, W.d_seg, W.d_seg_count, W.d_keys_xy, W.d_keys_score, W.d_keys_label, W.d_key_count, W.d_lvl_kp, W.d_lvl_cnt,
                                e->d_status, W.d_qt_spill, (unsigned long long)e->qt_spill_words);
     }
     {
@@ -1060,14 +1065,20 @@ int orbhip_debug_candidates(orbhip_extractor* e, int frame, int level, orbhip_ca
     const Workspace& W = e->ws[e->last_ws];
     HIP_TRY(e, hipMemcpy(&n, W.d_key_count + frame * P.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
     n = std::min(n, g.keys_cap);
-    std::vector<uint2> raw((size_t)std::max(n, 1));
-    HIP_TRY(e, hipMemcpy(raw.data(), W.d_keys + (size_t)frame * P.keys_per_frame + g.keys_off, (size_t)n * sizeof(uint2), hipMemcpyDeviceToHost));
+    const size_t kbase = (size_t)frame * P.keys_per_frame + g.keys_off;
+    const bool wide = P.qt_spill_slot[level] >= 0;              // 32-bit label words where the node arrays live in global memory
+    std::vector<uint32_t> xy((size_t)std::max(n, 1)), lab((size_t)std::max(n, 1));
+    std::vector<uint8_t> sc((size_t)std::max(n, 1));
+    HIP_TRY(e, hipMemcpy(xy.data(), W.d_keys_xy + kbase, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(sc.data(), W.d_keys_score + kbase, (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(lab.data(), W.d_keys_label + kbase, (size_t)n * (wide ? 4 : 2), hipMemcpyDeviceToHost));
     struct Item { unsigned ord; orbhip_candidate c; };
     std::vector<Item> items;
     for (int i = 0; i < n; i++) {
-        // keys the quadtree dropped by the per-cell threshold rule (src/ORBextractor.cc:808-816) carry the dead label
-        if ((raw[i].y >> 10) == ORB_DEAD_LABEL) continue;
-        const int x = raw[i].x & 0xFFFF, y = raw[i].x >> 16, s = raw[i].y & 0xFF;
+        // keys the quadtree dropped by the per-cell threshold rule (src/ORBextractor.cc:808-816) carry a label word of all ones
+        const uint32_t label = wide ? lab[(size_t)i] : reinterpret_cast<const uint16_t*>(lab.data())[i];
+        if (label == (wide ? 0xFFFFFFFFu : 0xFFFFu)) continue;
+        const int x = xy[(size_t)i] & 0xFFFF, y = xy[(size_t)i] >> 16, s = sc[(size_t)i];
         const int cx = (x - 3) / g.wcell, cy = (y - 3) / g.hcell;
         const unsigned ord = (unsigned)(((cy * g.ncols + cx) * g.hcell + (y - 3 - cy * g.hcell)) * g.wcell + (x - 3 - cx * g.wcell));
         items.push_back(Item{ord, orbhip_candidate{x, y, s}});
