@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--color", type=int, default=0, choices=[0, 3, 4], help="feed interleaved BGR(A) frames: gray conversion fused into level 0")
     ap.add_argument("--host-fed", action="store_true", help="also time the PCIe-inclusive host-buffer entry point")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for the barrier / max-time reduction")
+    ap.add_argument("--fast-th", default=None, help="INI,MIN: other FAST thresholds than the workload's (an experiment, named in config.fast_th)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses GPU 0 (use with --backend gloo)")
     args = ap.parse_args()
     if args.preset == "c4_strong_1024":
@@ -188,6 +189,8 @@ def main():
             dist.init_process_group("gloo")
 
     w, h, nfeat, scale, levels, ini_th, min_th = WORKLOADS[args.workload]
+    if args.fast_th:
+        ini_th, min_th = (int(v) for v in args.fast_th.split(","))
     ex = orbhip.ORBextractor(nfeat, scale, levels, ini_th, min_th, device=local_rank, max_batch=args.max_batch)
     cap = ex.max_keypoints()
     if args.rectify:

@@ -18,7 +18,7 @@
 #define ORB_EDGE 19           // EDGE_THRESHOLD (src/ORBextractor.cc:74)
 #define ORB_MINB 16           // minBorderX/Y = EDGE_THRESHOLD-3 (src/ORBextractor.cc:773)
 #define ORB_MAX_LEVELS 16
-#define ORB_HP_ITEMS 384      // 6 trips of a wave
+#define ORB_HP_ITEMS 192      // 3 trips of a wave
 
 struct RsTab {                // one bilinear tap pair of cv::resize (8 bytes)
     uint16_t s0, s1;          // source indices (already clamped)
@@ -73,10 +73,11 @@ struct PlanDev {
     // Byte weights of the orientation disc, one row of 32 bytes per |v| (byte i <-> u = i - 15):
     // words 0..7 hold 1 where |u| <= umax[|v|], words 8..15 hold u + 15 there; 0 elsewhere.
     uint32_t disc_w[16][16];
-    // Work items of the descriptor kernel's horizontal blur pass (4 adjacent sums of one row of the
-    // 45 x 40 grid of row sums per item), only where a rotated test point can ever need them (the
-    // pattern lies inside a circle of radius sqrt(338)): byte offset of the item's first pixel in the
-    // staged patch | byte offset of its first sum << 16; padded with repeats to ORB_HP_ITEMS.
+    // Work items of the descriptor kernel's horizontal blur pass (4 adjacent sums of an even row of the
+    // 45 x 40 grid of row sums and of the row below it per item), only where a rotated test point can
+    // ever need them (the pattern lies inside a circle of radius sqrt(338)): byte offset of the item's
+    // first pixel in the staged patch | byte offset of its first sum in the column-major array of sums
+    // << 16; padded with repeats to ORB_HP_ITEMS.
     uint32_t hp_items[ORB_HP_ITEMS];
     // k_fast handles all levels in one launch per kind of tile: workgroups [fast_cum[k][l] * frames,
     // fast_cum[k][l+1] * frames) belong to level l (running sum of that kind's tiles per frame); magics for

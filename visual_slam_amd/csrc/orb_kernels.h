@@ -934,8 +934,11 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
 // ------------------------------------------------------------------------------------------------
 #define DS_RAW_P 52               // raw patch pitch (13 dwords)
 #define DS_RAW_BYTES (45 * DS_RAW_P)
-#define DS_HP_P 40                // horizontal-pass pitch (u16 entries)
-#define DS_HP_ENTRIES (45 * DS_HP_P)
+#define DS_HP_P 46                // horizontal-pass pitch (u16 entries): the sums are kept column by column (45 rows of a
+                                  // column one after the other), so that the seven sums under a test point are 14 adjacent bytes;
+                                  // 23 dwords: neighbouring columns start in different banks
+#define DS_HP_ENTRIES (40 * DS_HP_P + 8)   // 40 columns (the last one is padding) and the tail of a 16-byte read
+struct __attribute__((packed, aligned(4))) HpWindow { uint32_t a, b, c, d; };   // eight sums read at dword alignment
 
 __device__ __align__(16) const signed char d_pattern[1024] = {
 #include "../../include/orb_pattern_31.inc"
@@ -1171,19 +1174,24 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     for (int k = 0; k < ORB_HP_ITEMS / 64; k++) items[k] = plan->hp_items[64 * k + lane];
 #pragma unroll
     for (int k = 0; k < ORB_HP_ITEMS / 64; k++) {
-        // sums c..c+3 of row r (column 39 is padding): the item holds both byte offsets
+        // sums c..c+3 of rows r and r+1 (r even; column 39 is padding): the item holds both byte offsets
         const uint32_t* rw = reinterpret_cast<const uint32_t*>(raw + (items[k] & 0xFFFF));
-        const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2];
-        uint32_t acc[4];
+        uint32_t acc[2][4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            // sum q: bytes q+k of the twelve times tap k: dword j holds the taps 4j-q .. 4j-q+3
-            uint32_t a = __builtin_amdgcn_udot4(d0, pat(-q), 0u, false);
-            a = __builtin_amdgcn_udot4(d1, pat(4 - q), a, false);
-            if (q >= 2) a = __builtin_amdgcn_udot4(d2, pat(8 - q), a, false);
-            acc[q] = a;
+        for (int rr = 0; rr < 2; rr++) {
+            const uint32_t d0 = rw[rr * (DS_RAW_P / 4)], d1 = rw[rr * (DS_RAW_P / 4) + 1], d2 = rw[rr * (DS_RAW_P / 4) + 2];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                // sum q: bytes q+k of the twelve times tap k: dword j holds the taps 4j-q .. 4j-q+3
+                uint32_t a = __builtin_amdgcn_udot4(d0, pat(-q), 0u, false);
+                a = __builtin_amdgcn_udot4(d1, pat(4 - q), a, false);
+                if (q >= 2) a = __builtin_amdgcn_udot4(d2, pat(8 - q), a, false);
+                acc[rr][q] = a;
+            }
         }
-        *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(hp) + (items[k] >> 16)) = make_uint2(acc[0] | (acc[1] << 16), acc[2] | (acc[3] << 16));
+        uint32_t* o = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(hp) + (items[k] >> 16));   // column c, rows r and r+1
+#pragma unroll
+        for (int q = 0; q < 4; q++) o[q * (DS_HP_P / 2)] = acc[0][q] | (acc[1][q] << 16);
     }
     // ---- steered BRIEF (src/ORBextractor.cc:107-147)
     const float factorPI = (float)(3.141592653589793238462643383279502884 / 180.f);
@@ -1193,6 +1201,9 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     const int ties_even = plan->blur_ties_even;
     const v2f_t ab = {a, b}, nba = {-b, a};
     const uint16_t* hp_top = hp + 19 * DS_HP_P + 19;          // row sums of (row offset -3, column offset 0) from the keypoint
+    // tap pairs for the dot products over the eight sums of a window (rows -3 .. +4; the last one gets weight 0)
+    const v2us_t w01 = {(unsigned short)t3, (unsigned short)t2}, w23 = {(unsigned short)t1, (unsigned short)t0};
+    const v2us_t w45 = {(unsigned short)t1, (unsigned short)t2}, w67 = {(unsigned short)t3, 0};
     // cvRound without conversions: adding 1.5 * 2^23 to a float of small magnitude rounds it to the nearest
     // integer, ties to even, and leaves 0x4B400000 + that integer in the bits of the sum. The two biased
     // integers go into the address as they are (the 24-bit multiply sees 0x400000 + ry); the biases are
@@ -1218,21 +1229,21 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
             const v2f_t pxv = v2f_t{px, px} * ab, pyv = v2f_t{py, py} * nba;
             const v2f_t rr = (pxv + pyv) + v2f_t{round_magic, round_magic};
             const int irx = __float_as_int(rr.x), iry = __float_as_int(rr.y);
-            // taps < 2^6, row sums < 2^17: full-rate 24-bit multiplies are exact. h = the top tap (row
-            // ry - 3), so that all seven reads have non-negative constant offsets (the index is made
-            // opaque to the compiler, which would otherwise spread the large bias over the seven reads).
-            int hidx = __mul24(iry, DS_HP_P) + irx - index_bias;
-            asm("" : "+v"(hidx));
-            const uint16_t* h = hp_top + hidx;
-            // the sum with the rounding half already in it
-            int m = __mul24(t0, h[3 * DS_HP_P]) + 0x8000;
-            m += __mul24(t1, h[2 * DS_HP_P] + h[4 * DS_HP_P]);
-            m += __mul24(t2, h[DS_HP_P] + h[5 * DS_HP_P]);
-            m += __mul24(t3, h[0] + h[6 * DS_HP_P]);
+            // the window starts at the top tap (column rx, row ry - 3): one 16-byte read, four dot products
+            // of sum pairs against tap pairs, the rounding half already in the sum
+            // (read from the dword the window starts in; a window that starts in its upper half is moved down
+            // by two bytes)
+            const int hidx = __mul24(irx, DS_HP_P) + iry - (index_bias - (19 * DS_HP_P + 19));
+            const HpWindow hw = *reinterpret_cast<const HpWindow*>(hp + (hidx & ~1));
+            const uint32_t sh = ((uint32_t)hidx & 1u) << 1;
+            uint32_t m = __builtin_amdgcn_udot2(__builtin_bit_cast(v2us_t, __builtin_amdgcn_alignbyte(hw.b, hw.a, sh)), w01, 0x8000u, false);
+            m = __builtin_amdgcn_udot2(__builtin_bit_cast(v2us_t, __builtin_amdgcn_alignbyte(hw.c, hw.b, sh)), w23, m, false);
+            m = __builtin_amdgcn_udot2(__builtin_bit_cast(v2us_t, __builtin_amdgcn_alignbyte(hw.d, hw.c, sh)), w45, m, false);
+            m = __builtin_amdgcn_udot2(__builtin_bit_cast(v2us_t, __builtin_amdgcn_alignbyte(0u, hw.d, sh)), w67, m, false);
             // round half up: m >> 16; an exact half (low 16 bits of m zero) that came out odd goes down to the
             // even value where the legacy rule applies
-            const bool tie_odd = ((uint32_t)m & 0x1FFFFu) == 0x10000u && irx < tie_limit;
-            const uint32_t qv = ((uint32_t)m >> 16) - (uint32_t)tie_odd;
+            const bool tie_odd = (m & 0x1FFFFu) == 0x10000u && irx < tie_limit;
+            const uint32_t qv = (m >> 16) - (uint32_t)tie_odd;
             val[e] = (int)min(qv, 255u);
         }
         bits[rnd] = __ballot(val[0] < val[1]);

@@ -268,16 +268,29 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
         for (int i = 0; i < 512; i++) r2 = std::max(r2, pat[2 * i] * pat[2 * i] + pat[2 * i + 1] * pat[2 * i + 1]);
         const double R = std::sqrt((double)r2) + 1e-3;
         const int ry_max = (int)std::floor(R + 0.5);
-        int n = 0;
+        // first / last column group a row needs (row = dy + 22; rows nobody reads have lo > hi)
+        int glo[46], ghi[46];
+        for (int r = 0; r < 46; r++) { glo[r] = 1; ghi[r] = 0; }
         for (int dy = -ry_max - 3; dy <= ry_max + 3; dy++) {
             const int ry = std::max(std::abs(dy) - 3, 0);
             const double t = R * R - std::max(ry - 0.5, 0.0) * std::max(ry - 0.5, 0.0);
             if (t < 0 || dy + 22 < 0 || dy + 22 > 44) continue;
             const int m = std::min((int)std::floor(0.5 + std::sqrt(t)), 19);
-            for (int g = (19 - m) >> 2; g <= std::min((19 + m) >> 2, 9); g++)
-                if (n < ORB_HP_ITEMS) P.hp_items[n++] = (uint32_t)((dy + 22) * DS_RAW_P + 4 * g) | ((uint32_t)(((dy + 22) * DS_HP_P + 4 * g) * 2) << 16);
+            glo[dy + 22] = (19 - m) >> 2; ghi[dy + 22] = std::min((19 + m) >> 2, 9);
+        }
+        // an item covers the same four columns of an even row and the row below it (their sums share a dword
+        // of the column-major array)
+        int n = 0;
+        for (int r = 0; r < 44; r += 2) {
+            const bool a = glo[r] <= ghi[r], b = glo[r + 1] <= ghi[r + 1];
+            if (!a && !b) continue;
+            const int lo = a && b ? std::min(glo[r], glo[r + 1]) : a ? glo[r] : glo[r + 1];
+            const int hi = a && b ? std::max(ghi[r], ghi[r + 1]) : a ? ghi[r] : ghi[r + 1];
+            for (int g = lo; g <= hi; g++)
+                if (n < ORB_HP_ITEMS) P.hp_items[n++] = (uint32_t)(r * DS_RAW_P + 4 * g) | ((uint32_t)((4 * g * DS_HP_P + r) * 2) << 16);
                 else { e->err = "internal: blur work list overflow"; return ORBHIP_ERR_ARG; }
         }
+        if (glo[44] <= ghi[44]) { e->err = "internal: blur work list expects an even number of rows"; return ORBHIP_ERR_ARG; }
         for (int i = n; i < ORB_HP_ITEMS; i++) P.hp_items[i] = P.hp_items[i - n];   // repeats write the same values again
     }
     size_t pyr_off = 0, keys_off = 0, seg_off = 0;
