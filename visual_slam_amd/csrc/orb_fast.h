@@ -119,7 +119,9 @@ __device__ __forceinline__ v2s fast_score16_pk(v2s v, const v2s (&p)[16]) {
 #define FT_IMG_ROWS 40     // tile rows -4 .. 35
 #define FT_QUEUE 256       // compaction window per wave
 #define FT_SEGCAP 768      // output segment of one wave: a quarter of a tile's survivors (< 2000) plus a batch, or 8 rows x 248 columns
+#ifndef FT_LIST
 #define FT_LIST 832        // scored output pixels a tile can list (sized so that 7 workgroups fit a CU's LDS)
+#endif
 
 // Inclusive prefix sum over the 64 lanes with DPP row shifts and row broadcasts.
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
