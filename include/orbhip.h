@@ -141,6 +141,11 @@ int orbhip_pyramid_copy(orbhip_extractor* e, int frame, int level, uint8_t* dst,
  * Returns the count (which may exceed cap) or a negative error. */
 typedef struct orbhip_candidate { int x, y, response; } orbhip_candidate;
 int orbhip_debug_candidates(orbhip_extractor* e, int frame, int level, orbhip_candidate* out, int cap);
+/* Diagnostic: the keypoints the quadtree left for one level of one frame of the last pass, in list order
+ * (the output of DistributeOctTree, src/ORBextractor.cc:539-763, before orientation and descriptors):
+ * x, y (level coordinates) and FAST score per keypoint, three 16-bit values each. Returns the count
+ * (which may exceed cap), or a negative status. */
+int orbhip_debug_level_keypoints(orbhip_extractor* e, int frame, int level, uint16_t* out_xys, int cap);
 
 /* Diagnostics for parity tests: the cosine and sine the descriptor kernel uses for its rotation (the
  * reference calls cosf / sinf of the keypoint angle in radians, src/ORBextractor.cc:113-114) for the

@@ -114,6 +114,10 @@ struct LevelKp {              // keypoint of one level after the quadtree, level
 static inline unsigned grid_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
 
 #ifdef __HIPCC__
+// Unsigned 24-bit multiply (low 32 bits of the product). HIP declares __umul24 with an int result: a product
+// of 2^31 or more would then be shifted arithmetically (the cell divisions below shift by 22).
+__device__ __forceinline__ uint32_t umul24(uint32_t a, uint32_t b) { return (uint32_t)__umul24(a, b); }
+
 // Workgroups are dealt to the 8 XCDs (each with its own L2) round-robin in dispatch order, so
 // tiles that are neighbours in the image would land on different L2s and each fetch the rows and
 // cache lines they share from memory again. This remap gives every group of workgroups that

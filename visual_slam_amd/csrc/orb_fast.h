@@ -189,7 +189,7 @@ struct FastBands {
 template <bool PACKED>
 __device__ __forceinline__ bool fast_is_output(int row, int xl, const FastBands& fb) {
     if (!PACKED) return (unsigned)(row - 1) < (unsigned)FT_ROWS && (unsigned)(xl - 4) < (unsigned)FT_COLS;
-    const int ln = xl >> 2, li = ln - __mul24((int)(__umul24((uint32_t)ln, fb.magic) >> 16), fb.lpb);
+    const int ln = xl >> 2, li = ln - __mul24((int)(umul24((uint32_t)ln, fb.magic) >> 16), fb.lpb);
     return (unsigned)(row - 1) < (unsigned)FT_ROWS && (unsigned)(li - 1) < (unsigned)(fb.lpb - 2);
 }
 
@@ -262,7 +262,7 @@ __device__ __forceinline__ void fast_tile(const LevelGeom& g, const uint8_t* __r
     int band = 0, li = lane;
     bool band_ok = true;
     if (PACKED) {
-        band = (int)(__umul24((uint32_t)lane, fb.magic) >> 16);
+        band = (int)(umul24((uint32_t)lane, fb.magic) >> 16);
         li = lane - __mul24(band, fb.lpb);
         band_ok = band < fb.nbands;
     }
@@ -419,13 +419,13 @@ __device__ __forceinline__ void fast_tile(const LevelGeom& g, const uint8_t* __r
             s = c[0];
             x = xs - 4 + xl; y = y0 - 1 + m;
             if (PACKED) {
-                const int bb = (int)(__umul24((uint32_t)(xl >> 2), fb.magic) >> 16);   // the pixel's band
+                const int bb = (int)(umul24((uint32_t)(xl >> 2), fb.magic) >> 16);   // the pixel's band
                 x -= __mul24(bb, 4 * fb.lpb); y += __mul24(bb, FT_ROWS);
             }
             const int ux = x - ORB_EDGE, uy = y - ORB_EDGE;
             // position inside the cell: n / d == n * ceil(2^22 / d) >> 22 for n * d < 2^22 (full-rate multiplies)
-            const int xin = ux - __mul24((int)(__umul24((uint32_t)ux, g.wcell_m22) >> 22), g.wcell);
-            const int yin = uy - __mul24((int)(__umul24((uint32_t)uy, g.hcell_m22) >> 22), g.hcell);
+            const int xin = ux - __mul24((int)(umul24((uint32_t)ux, g.wcell_m22) >> 22), g.wcell);
+            const int yin = uy - __mul24((int)(umul24((uint32_t)uy, g.hcell_m22) >> 22), g.hcell);
             const bool l = xin > 0, r = xin < g.wcell - 1, u = yin > 0, d = yin < g.hcell - 1;
             // all eight reads are in range (the map has a one-pixel halo); issue them together
             const int nw_ = c[-FT_P - 1], n_ = c[-FT_P], ne_ = c[-FT_P + 1], w_ = c[-1], e_ = c[1];

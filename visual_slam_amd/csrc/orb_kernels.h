@@ -427,7 +427,7 @@ __device__ __forceinline__ void resize_rows(const uint8_t* __restrict__ src, uin
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             hprev[i] = h1[i];
-            const uint32_t p0 = __umul24(b0, h0[i]) + 0x20000u, p1 = __umul24(b1, h1[i]);
+            const uint32_t p0 = umul24(b0, h0[i]) + 0x20000u, p1 = umul24(b1, h1[i]);
             if (i & 1)
                 asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1"
                     : "+v"(pair[i >> 1]) : "v"(p0), "v"(p1));
@@ -654,8 +654,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
                 ksc[p] = (uint8_t)e[u].y;
                 if ((int)(e[u].y & 0xFF) >= ini_th) {
                     const int x = e[u].x & 0xFFFF, y = e[u].x >> 16;
-                    const int c = __mul24((int)(__umul24((uint32_t)(y - 3), g.hcell_m22) >> 22), g.ncols) +
-                                  (int)(__umul24((uint32_t)(x - 3), g.wcell_m22) >> 22);
+                    const int c = __mul24((int)(umul24((uint32_t)(y - 3), g.hcell_m22) >> 22), g.ncols) +
+                                  (int)(umul24((uint32_t)(x - 3), g.wcell_m22) >> 22);
                     atomicOr(&cellbits[c >> 5], 1u << (c & 31));
                 }
             }
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
 #pragma unroll
         for (int u = 0; u < QT_KU; u++) {
             x[u] = exy[u] & 0xFFFF; y[u] = exy[u] >> 16; s[u] = (int)esc[u];
-            cell[u] = __mul24((int)(__umul24((uint32_t)(y[u] - 3), g.hcell_m22) >> 22), g.ncols) + (int)(__umul24((uint32_t)(x[u] - 3), g.wcell_m22) >> 22);
+            cell[u] = __mul24((int)(umul24((uint32_t)(y[u] - 3), g.hcell_m22) >> 22), g.ncols) + (int)(umul24((uint32_t)(x[u] - 3), g.wcell_m22) >> 22);
             cb[u] = cellbits[cell[u] >> 5];
             root[u] = min(max((int)__fdiv_rn((float)x[u], g.hx), 0), L - 1);
             b0[u] = q.box[0][2 * root[u]]; b1[u] = q.box[0][2 * root[u] + 1];
@@ -891,12 +891,12 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
                 for (int u = 0; u < QT_KU; u++) {
                     if (!alive[u]) continue;
                     const int x = exy[u] & 0xFFFF, y = exy[u] >> 16;
-                    const int cx = (int)(__umul24((uint32_t)(x - 3), g.wcell_m22) >> 22);
-                    const int cy = (int)(__umul24((uint32_t)(y - 3), g.hcell_m22) >> 22);
+                    const int cx = (int)(umul24((uint32_t)(x - 3), g.wcell_m22) >> 22);
+                    const int cy = (int)(umul24((uint32_t)(y - 3), g.hcell_m22) >> 22);
                     // (every factor stays below 2^24 and every product below 2^32: full-rate 24-bit multiplies)
-                    const uint32_t row_in_cells = __umul24((uint32_t)(__mul24(cy, g.ncols) + cx), (uint32_t)g.hcell) +
+                    const uint32_t row_in_cells = umul24((uint32_t)(__mul24(cy, g.ncols) + cx), (uint32_t)g.hcell) +
                                                   (uint32_t)(y - 3 - __mul24(cy, g.hcell));
-                    const uint32_t ord = __umul24(row_in_cells, (uint32_t)g.wcell) + (uint32_t)(x - 3 - __mul24(cx, g.wcell));
+                    const uint32_t ord = umul24(row_in_cells, (uint32_t)g.wcell) + (uint32_t)(x - 3 - __mul24(cx, g.wcell));
                     atomicMax(&q.key64[nl[u]], ((unsigned long long)sc[u] << 32) | (0xFFFFFFFFu - ord));
                 }
             });

@@ -113,6 +113,8 @@ struct orbhip_extractor {
     RsTab* d_tabs = nullptr;
     Workspace ws[kLanes];
     int plan_lanes = 0;            // workspaces allocated for the current plan
+    bool debug_skip_describe = false;   // ORBHIP_DEBUG_SKIP_DESCRIBE=1: stop after the quadtree (orbhip_debug_level_keypoints shows its output)
+    bool debug_sync = false;       // ORBHIP_DEBUG_SYNC=1: wait after every group of launches and name the one that failed
     int max_lanes = 1;             // ORBHIP_LANES=2..4: that many passes of a large batch in flight (a few % more throughput)
     hipEvent_t ev_fork = nullptr;
     size_t qt_lds_limit = 160 * 1024 - 256;   // node arrays of a level beyond this many bytes live in global memory (ORBHIP_QT_LDS_LIMIT)
@@ -500,6 +502,17 @@ void launch_level0(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8
     }
 }
 
+// ORBHIP_DEBUG_SYNC: the stream is drained after a group of launches so that a failing kernel is named.
+static int debug_sync_point(orbhip_extractor* e, hipStream_t s, const char* what) {
+    if (!e->debug_sync) return ORBHIP_OK;
+    const hipError_t st = hipStreamSynchronize(s);
+    if (st == hipSuccess) return ORBHIP_OK;
+    static thread_local char msg[160];
+    std::snprintf(msg, sizeof msg, "%s failed: %s", what, hipGetErrorString(st));
+    e->err = msg;
+    return ORBHIP_ERR_HIP;
+}
+
 // One pass: `frames` frames starting at device pointer d_imgs; outputs written at frame index frame0.
 // channels: 1 (gray), 3 or 4 (interleaved colour, converted to gray on the way in); rgb: channel 0 is red.
 // row_readable: bytes of every row (the last row of the last frame included) that belong to the buffer.
@@ -524,6 +537,7 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
         SpanGuard t(e, s, KC_LEVEL0);
         if (!inplace) launch_level0(e, W, s, d_imgs, frames, row_stride, frame_stride, channels, rgb, true);
     }
+    if (int rc = debug_sync_point(e, s, "level 0")) return rc;
     // FAST is bound by vector issue, the resize chain by memory: with `overlap` level 0's FAST runs on
     // a second stream beside the chain and the remaining levels follow on the main stream
     const unsigned split = (e->overlap && nl > 1) ? P.fast_cum[0][1] * (unsigned)frames : 0u;
@@ -562,6 +576,7 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
         else
             hipLaunchKernelGGL((k_resize<false, false>), grid, blk2, 0, s, W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g,
                                e->d_tabs, c4_end, 0, 0);
+        if (int rc = debug_sync_point(e, s, "k_resize")) return rc;
     }
     {                                                          // all (remaining) levels in one launch per kind of tile
         SpanGuard t(e, s, KC_FAST);
@@ -573,6 +588,7 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
                                W.d_pyr, e->d_plan, frames, W.d_seg, W.d_seg_count, e->d_status, 0u, W.v0);
     }
     if (split) HIP_TRY(e, hipStreamWaitEvent(s, e->ev_f0, 0));
+    if (int rc = debug_sync_point(e, s, "k_fast")) return rc;
     {
         SpanGuard t(e, s, KC_QUADTREE);
         if (P.qt_nspill < nl)
@@ -584,7 +600,9 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
                                e->d_plan, W.d_seg, W.d_seg_count, W.d_keys_xy, W.d_keys_score, W.d_keys_label, W.d_key_count, W.d_lvl_kp, W.d_lvl_cnt,
                                e->d_status, W.d_qt_spill, (unsigned long long)e->qt_spill_words);
     }
-    {
+    if (int rc = debug_sync_point(e, s, "k_quadtree")) return rc;
+    if (e->debug_skip_describe) HIP_TRY(e, hipMemsetAsync(d_counts + frame0, 0, (size_t)frames * sizeof(int), s));
+    else {
         SpanGuard t(e, s, KC_DESCRIBE);
         const int maxkp = std::min(cap, P.kp_per_frame);
         const int ngroups = (maxkp + 3) / 4;                  // 4 keypoints per workgroup
@@ -594,6 +612,7 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
                            e->d_plan, W.d_pyr, W.d_lvl_kp, W.d_lvl_cnt, d_kp, d_desc, d_counts, cap, frame0, e->d_status,
                            frames, ngroups, grid_magic(8u * (unsigned)ngroups), W.v0);
     }
+    if (int rc = debug_sync_point(e, s, "k_describe")) return rc;
     HIP_TRY(e, hipGetLastError());
     e->last_pass_frames = frames;
     e->last_ws = (int)(&W - e->ws);
@@ -690,6 +709,8 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
         ok = ok && hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&w.done, hipEventDisableTiming) == hipSuccess;
     if (!ok) { orbhip_destroy(e); return ORBHIP_ERR_HIP; }
+    if (const char* v = std::getenv("ORBHIP_DEBUG_SKIP_DESCRIBE")) e->debug_skip_describe = std::atoi(v) != 0;
+    if (const char* v = std::getenv("ORBHIP_DEBUG_SYNC")) e->debug_sync = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_LANES")) e->max_lanes = std::min(kLanes, std::max(1, std::atoi(v)));
     if (const char* v = std::getenv("ORBHIP_OVERLAP")) e->overlap = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_INPLACE_LEVEL0")) e->inplace_l0 = std::atoi(v) != 0;
@@ -1099,6 +1120,23 @@ int orbhip_debug_candidates(orbhip_extractor* e, int frame, int level, orbhip_ca
     std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.ord < b.ord; });
     for (size_t i = 0; i < items.size() && (int)i < cap; i++) out[i] = items[i].c;
     return (int)items.size();
+}
+
+int orbhip_debug_level_keypoints(orbhip_extractor* e, int frame, int level, uint16_t* out_xys, int cap) {
+    if (!e || level < 0 || level >= e->prm.nlevels) return ORBHIP_ERR_ARG;
+    if (!e->plan_w || frame < 0 || frame >= e->last_pass_frames) return ORBHIP_ERR_STATE;
+    const PlanDev& P = e->plan;
+    const LevelGeom& g = P.lv[level];
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipDeviceSynchronize());
+    const Workspace& W = e->ws[e->last_ws];
+    int n = 0;
+    HIP_TRY(e, hipMemcpy(&n, W.d_lvl_cnt + frame * P.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    const int m = std::max(0, std::min(std::min(n, g.node_cap), cap));
+    std::vector<LevelKp> kp((size_t)std::max(m, 1));
+    HIP_TRY(e, hipMemcpy(kp.data(), W.d_lvl_kp + (size_t)frame * P.kp_per_frame + g.kp_off, (size_t)m * sizeof(LevelKp), hipMemcpyDeviceToHost));
+    for (int i = 0; i < m; i++) { out_xys[3 * i] = kp[(size_t)i].x; out_xys[3 * i + 1] = kp[(size_t)i].y; out_xys[3 * i + 2] = kp[(size_t)i].score; }
+    return n;
 }
 
 int orbhip_enable_timing(orbhip_extractor* e, int on) {

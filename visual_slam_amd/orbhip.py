@@ -29,7 +29,7 @@ EXPORTS = [
     "orbhip_get_scale_factor", "orbhip_get_scale_factors", "orbhip_get_inverse_scale_factors",
     "orbhip_get_scale_sigma_squares", "orbhip_get_inverse_scale_sigma_squares",
     "orbhip_get_features_per_level", "orbhip_get_umax", "orbhip_pyramid_info", "orbhip_pyramid_copy",
-    "orbhip_debug_candidates", "orbhip_enable_timing", "orbhip_get_timing", "orbhip_strerror",
+    "orbhip_debug_candidates", "orbhip_debug_level_keypoints", "orbhip_enable_timing", "orbhip_get_timing", "orbhip_strerror",
     "orbhip_last_error", "orbhip_stereo_match", "orbhip_stereo_match_batch_device",
     "orbhip_stereo_match_batch_device_noalloc", "orbhip_extract_stereo_batch_device",
     "orbhip_extract_color", "orbhip_extract_batch_device_color",
@@ -89,6 +89,7 @@ def lib():
         L.orbhip_pyramid_info.argtypes = [vp, C.c_int, ip, ip]
         L.orbhip_pyramid_copy.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t, C.c_int]
         L.orbhip_debug_candidates.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+        L.orbhip_debug_level_keypoints.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
         L.orbhip_enable_timing.argtypes = [vp, C.c_int]
         L.orbhip_get_timing.argtypes = [vp, C.POINTER(C.c_char_p), fp, ip, C.c_int]
         L.orbhip_strerror.argtypes = [C.c_int]
@@ -564,6 +565,14 @@ class ORBextractor:
         out = np.zeros(max(n, 1), CAND_DTYPE)
         lib().orbhip_debug_candidates(self._h, frame, level, _ptr(out), n)
         return out[:n]
+
+    def debug_level_keypoints(self, level, frame=0, cap=65536):
+        """(n, 3) uint16 array of x, y, score: what the quadtree left for `level`, in list order."""
+        out = np.zeros((cap, 3), np.uint16)
+        n = lib().orbhip_debug_level_keypoints(self._h, frame, level, _ptr(out), cap)
+        if n < 0:
+            raise OrbHipError(n)
+        return out[:min(n, cap)]
 
     def enable_timing(self, on=True):
         self._check(lib().orbhip_enable_timing(self._h, int(on)))
