@@ -114,8 +114,13 @@ int orbhip_extract_batch_device_color(orbhip_extractor* e, const uint8_t* d_imgs
 int orbhip_synchronize(orbhip_extractor* e);
 
 /* Upper bound of keypoints one frame can yield (sum over levels of quota + slack of the quadtree,
- * src/ORBextractor.cc:669-673,728-731): size `cap` with it. */
+ * src/ORBextractor.cc:669-673,728-731): size `cap` with it. Holds for images whose levels have at most 16
+ * initial quadtree nodes each (round(width / height) of a level's detection window, src/ORBextractor.cc:543:
+ * every camera format); the first round of the distribution yields up to 4 nodes per initial node whatever
+ * the quota (:594-665), so wide strips can exceed it: */
 int orbhip_max_keypoints(const orbhip_extractor* e);
+/* The bound for images of one size (any aspect ratio the extractor accepts). */
+int orbhip_max_keypoints_for_image(const orbhip_extractor* e, int width, int height);
 
 /* Accessors (include/ORBextractor.h:63-83). Array getters fill nlevels floats. */
 int orbhip_get_levels(const orbhip_extractor* e);                               /* GetLevels */

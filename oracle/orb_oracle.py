@@ -125,7 +125,8 @@ class OracleExtractor:
     def extract(self, img):
         img = np.ascontiguousarray(img, dtype=np.uint8)
         h, w = img.shape
-        cap = self.nfeatures + 68 * self.nlevels + 64      # a level can keep 4 nodes per initial node whatever its quota
+        # a level can keep 4 nodes per initial node whatever its quota, and has at most width / 30 initial nodes
+        cap = self.nfeatures + (68 + 4 * (w // 30 + 1)) * self.nlevels + 64
         kp = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         n = C.c_int(0)

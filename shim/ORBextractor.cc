@@ -64,7 +64,7 @@ void ORBextractor::operator()( cv::InputArray _image, cv::InputArray _mask, std:
     cv::Mat image = _image.getMat();
     assert(image.type() == CV_8UC1 );
 
-    const int cap = orbhip_max_keypoints(mpHandle);
+    const int cap = orbhip_max_keypoints_for_image(mpHandle, image.cols, image.rows);
     std::vector<orbhip_keypoint> kps(cap);
     std::vector<unsigned char> desc((size_t)cap * 32);
     int n = 0;

@@ -76,6 +76,41 @@ def test_outputs_large(mods, name):
         print(name, kind, {k: v for k, v in r.items() if k != "desc_bad"})
 
 
+# Sizes at the limit of 16384 pixels per side. A level wider (taller) than 15 900 pixels has more than 512 cell
+# columns (rows): the cell divisions of the FAST suppression and of the quadtree are 24-bit multiplies whose
+# product then reaches 2^31 (once shifted as a signed number: keypoints outside the image). A wide strip also
+# has hundreds of initial quadtree nodes per level (src/ORBextractor.cc:543), whose first round alone yields
+# more keypoints than the quota (:594-665): the output capacity must come from the image size.
+EXTREME = {
+    "strip_16384x96": (16384, 96, 3000, 1.2, 8, 20, 7, "blocks"),
+    "strip_16000x200_12_levels": (16000, 200, 1000, 1.1, 12, 20, 7, "lowc"),
+    "tall_8320x16384": (8320, 16384, 3000, 1.2, 3, 20, 7, "blocks"),
+    "wide_16384x1024": (16384, 1024, 6000, 1.2, 8, 20, 7, "noise"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(EXTREME))
+def test_extreme_sizes(mods, name):
+    orbhip, O = mods
+    w, h, nf, sf, nl, ini, mn, kind = EXTREME[name]
+    img = synth.frame(kind, w, h, 3)
+    g, o = orbhip.ORBextractor(nf, sf, nl, ini, mn), O.OracleExtractor(nf, sf, nl, ini, mn)
+    okp, odesc = o.extract(img)
+    assert len(okp) <= g.max_keypoints(w, h)
+    # the quadtree's keypoints first: all inside their level (a keypoint outside it would send the descriptor
+    # kernel out of the image's memory)
+    gkp, gdesc = g(img, fetch_pyramid=False)
+    for l in range(nl):
+        gc, oc = g.debug_candidates(l), o.candidates(l)
+        assert len(gc) == len(oc) and np.array_equal(gc, oc), "candidate list of level %d" % l
+        d = g.debug_level_keypoints(l).astype(int)
+        lh, lw = o.level(l).shape
+        assert not len(d) or (d[:, 0].min() >= 19 and d[:, 1].min() >= 19 and d[:, 0].max() < lw - 19 and d[:, 1].max() < lh - 19), l
+    r = compare_outputs(gkp, gdesc, okp, odesc)
+    assert r["desc_exact"] >= DESC_MIN_EXACT, r
+    print(name, {k: v for k, v in r.items() if k != "desc_bad"})
+
+
 def test_const_and_empty(mods):
     orbhip, O = mods
     g = orbhip.ORBextractor(1000, 1.2, 8, 20, 7)

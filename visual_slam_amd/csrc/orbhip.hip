@@ -1001,6 +1001,22 @@ int orbhip_max_keypoints(const orbhip_extractor* e) {
     return total;
 }
 
+int orbhip_max_keypoints_for_image(const orbhip_extractor* e, int width, int height) {
+    if (!e || width < 1 || height < 1) return ORBHIP_ERR_ARG;
+    // The bound of orbhip_max_keypoints assumes at most 16 initial nodes per level. The distribution's first
+    // round yields up to 4 nodes per initial node whatever the quota (src/ORBextractor.cc:594-665), and a level
+    // has round(width / height) initial nodes of its detection window (:543): wide strips exceed that bound.
+    int total = 0;
+    for (int l = 0; l < e->prm.nlevels; l++) {
+        const int w = cv_round((float)width * e->inv_sf[l]), h = cv_round((float)height * e->inv_sf[l]);
+        const float ww = (float)(w - 2 * ORB_MINB), wh = (float)(h - 2 * ORB_MINB);
+        if (ww < 30.f || wh < 30.f) continue;                  // no cell, no keypoints
+        const int n_ini = (int)std::round(ww / (float)(h - 2 * ORB_MINB));
+        total += std::max(std::max(e->per_level[l] + 3, 4 * n_ini), 64) + 1;
+    }
+    return std::max(total, 1);
+}
+
 int orbhip_get_levels(const orbhip_extractor* e) { return e ? e->prm.nlevels : ORBHIP_ERR_ARG; }
 float orbhip_get_scale_factor(const orbhip_extractor* e) { return e ? (float)e->scale_factor_d : 0.f; }
 static int copy_table(const orbhip_extractor* e, const std::vector<float>& t, float* out) {

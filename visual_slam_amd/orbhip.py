@@ -25,7 +25,7 @@ OK, ERR_ARG, ERR_EMPTY, ERR_CAPACITY, ERR_GEOMETRY, ERR_HIP, ERR_NO_DEVICE, ERR_
 # every symbol include/orbhip.h declares
 EXPORTS = [
     "orbhip_create", "orbhip_destroy", "orbhip_extract", "orbhip_extract_batch_device",
-    "orbhip_extract_batch", "orbhip_synchronize", "orbhip_max_keypoints", "orbhip_get_levels",
+    "orbhip_extract_batch", "orbhip_synchronize", "orbhip_max_keypoints", "orbhip_max_keypoints_for_image", "orbhip_get_levels",
     "orbhip_get_scale_factor", "orbhip_get_scale_factors", "orbhip_get_inverse_scale_factors",
     "orbhip_get_scale_sigma_squares", "orbhip_get_inverse_scale_sigma_squares",
     "orbhip_get_features_per_level", "orbhip_get_umax", "orbhip_pyramid_info", "orbhip_pyramid_copy",
@@ -78,6 +78,7 @@ def lib():
         L.orbhip_extract_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, vp, vp, vp, C.c_int]
         L.orbhip_synchronize.argtypes = [vp]
         L.orbhip_max_keypoints.argtypes = [vp]
+        L.orbhip_max_keypoints_for_image.argtypes = [vp, C.c_int, C.c_int]
         L.orbhip_get_levels.argtypes = [vp]
         L.orbhip_get_scale_factor.argtypes = [vp]
         L.orbhip_get_scale_factor.restype = C.c_float
@@ -450,7 +451,7 @@ class ORBextractor:
         if image.strides[1] != 1:
             image = np.ascontiguousarray(image)
         h, w = image.shape
-        cap = self.max_keypoints()
+        cap = self.max_keypoints(w, h)
         kp = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         n = C.c_int(0)
@@ -464,7 +465,7 @@ class ORBextractor:
         Tracking::GrabImage* (reference src/Tracking.cc:166-191) done on the device; rgb = mbRGB."""
         image = np.ascontiguousarray(image, np.uint8)
         h, w, cn = image.shape
-        cap = self.max_keypoints()
+        cap = self.max_keypoints(w, h)
         kp = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         n = C.c_int(0)
@@ -478,7 +479,7 @@ class ORBextractor:
         """operator() over a (F,H,W) uint8 array of independent frames (host buffers)."""
         images = np.ascontiguousarray(images, np.uint8)
         f, h, w = images.shape
-        cap = self.max_keypoints()
+        cap = self.max_keypoints(w, h)
         kp = np.zeros((f, cap), KP_DTYPE)
         desc = np.zeros((f, cap, 32), np.uint8)
         counts = np.zeros(f, np.int32)
@@ -511,8 +512,12 @@ class ORBextractor:
     def synchronize(self):
         self._check(lib().orbhip_synchronize(self._h))
 
-    def max_keypoints(self):
-        return lib().orbhip_max_keypoints(self._h)
+    def max_keypoints(self, width=None, height=None):
+        """Output capacity to provide: for any camera format, or (with a size) for images of that size,
+        which matters for wide strips (see include/orbhip.h)."""
+        if width is None:
+            return lib().orbhip_max_keypoints(self._h)
+        return lib().orbhip_max_keypoints_for_image(self._h, int(width), int(height))
 
     # ---- accessors (include/ORBextractor.h:63-83) ----------------------------------------------
     def GetLevels(self):
