@@ -118,8 +118,8 @@ class OracleExtractor:
         self.nfeatures, self.nlevels = nfeatures, nlevels
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orbo_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:     # (at interpreter shutdown the module may already be gone)
+            _lib.orbo_destroy(self._h)
             self._h = None
 
     def extract(self, img):

@@ -111,6 +111,32 @@ def test_extreme_sizes(mods, name):
     print(name, {k: v for k, v in r.items() if k != "desc_bad"})
 
 
+def test_more_frames_than_a_grid_coordinate_holds(mods):
+    """70 000 small frames in one call with max_batch far above them: the frame index is a grid coordinate of
+    several launches (at most 65535), so a pass stops there and the rest follows in a second one."""
+    import torch
+    orbhip, O = mods
+    w, h, n, prm = 96, 96, 70000, (200, 1.2, 3, 20, 7)
+    dev = torch.device("cuda", 0)
+    base = np.stack([synth.frame("blocks", w, h, i) for i in range(64)])
+    frames = torch.from_numpy(base).to(dev).repeat((n + 63) // 64, 1, 1)[:n].contiguous()
+    g = orbhip.ORBextractor(*prm, max_batch=100000)
+    cap = g.max_keypoints(w, h)
+    kp = torch.empty((n, cap, 7), dtype=torch.float32, device=dev)
+    de = torch.empty((n, cap, 32), dtype=torch.uint8, device=dev)
+    cnt = torch.zeros((n,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    g.extract_batch_device(frames.data_ptr(), n, w, h, w, w * h, kp.data_ptr(), de.data_ptr(), cnt.data_ptr(), cap)
+    g.synchronize()
+    torch.cuda.synchronize()
+    c = cnt.cpu().numpy()
+    for i in (0, 63, 65534, 65535, 65536, n - 1):
+        okp, od = O.OracleExtractor(*prm).extract(base[i % 64])
+        k = kp[i, :c[i]].cpu().numpy()
+        assert c[i] == len(okp) and np.array_equal(k[:, 0], okp["x"]) and np.array_equal(k[:, 1], okp["y"]), i
+        assert np.array_equal(de[i, :c[i]].cpu().numpy(), od), i
+
+
 def test_const_and_empty(mods):
     orbhip, O = mods
     g = orbhip.ORBextractor(1000, 1.2, 8, 20, 7)

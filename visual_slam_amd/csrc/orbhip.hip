@@ -759,7 +759,8 @@ static int pass_budget(const orbhip_extractor* e, int width, int height) {
     const int ws_limit = std::max(1, (int)(24e9 / ws_per_frame));
     const unsigned long long groups = ((unsigned long long)orbhip_max_keypoints(e) + 3) / 4;
     const int grid_limit = (int)std::min<unsigned long long>(1u << 20, 8ull * (((1ull << 26) - 1) / (groups * groups)));
-    return std::max(1, std::min(std::min(e->prm.max_batch, ws_limit), std::max(grid_limit, 8)));
+    // (the frame index is the y or z coordinate of several grids: at most 65535)
+    return std::max(1, std::min(std::min(std::min(e->prm.max_batch, ws_limit), std::max(grid_limit, 8)), 65535));
 }
 
 static int extract_device_impl(orbhip_extractor* e, const uint8_t* d_imgs, int nframes, int width, int height,

@@ -426,8 +426,8 @@ class ORBextractor:
         self.mvImagePyramid = []
 
     def close(self):
-        if getattr(self, "_h", None):
-            lib().orbhip_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:     # (at interpreter shutdown the module may already be gone)
+            _lib.orbhip_destroy(self._h)
             self._h = None
 
     __del__ = close
