@@ -31,6 +31,8 @@ def draws(n, seed, max_mp):
     while len(out) < n:
         w = int(round(np.exp(rng.uniform(np.log(64), np.log(16384)))))
         h = int(round(np.exp(rng.uniform(np.log(64), np.log(16384)))))
+        if h > 1.9 * w and rng.random() < 0.8:
+            w, h = h, w                                        # (both sides refuse most portrait strips: nIni == 0)
         if w * h > max_mp * 1e6:
             continue
         nf = int(rng.choice([100, 500, 1000, 2000, 5000, 12000]))
@@ -48,7 +50,13 @@ def main():
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-mp", type=float, default=24.0, help="largest image area drawn, in megapixels")
+    ap.add_argument("--variants", action="store_true",
+                    help="also run every accepted draw device-resident with padded rows and an offset start (level 0 read in place "
+                         "where the alignment allows) and as a 3-channel image through the gray conversion: both must equal the plain result")
     args = ap.parse_args()
+    if args.variants:
+        import torch                                           # (before the library's first HIP call: torch brings its own runtime)
+        torch.cuda.init()
     bad = refused = 0
     for case in draws(args.cases, args.seed, args.max_mp):
         w, h, nf, sf, nl, ini, mn, kind, index = case
@@ -96,6 +104,37 @@ def main():
             bad += 1; print(tag, "MISMATCH", r, flush=True)
         elif len(gkp) and index % 10 == 0:
             print(tag, "ok,", len(gkp), "keypoints", flush=True)
+        if args.variants:
+            import torch
+            dev = torch.device("cuda:0")
+            pad, off = 4 * (index % 5), 4 * (index % 3) + (index % 7 == 0)      # (an odd offset now and then: the copied route)
+            rs = w + pad
+            buf = torch.full((off + h * rs,), 0xA5, dtype=torch.uint8, device=dev)
+            buf[off:].view(h, rs)[:, :w] = torch.from_numpy(img).to(dev)
+            cap = g.max_keypoints(w, h)
+            kp = torch.zeros((1, cap, 7), dtype=torch.float32, device=dev)
+            de = torch.zeros((1, cap, 32), dtype=torch.uint8, device=dev)
+            cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            g2 = orbhip.ORBextractor(nf, sf, nl, ini, mn)
+            try:
+                g2.extract_batch_device(buf.data_ptr() + off, 1, w, h, rs, h * rs, kp.data_ptr(), de.data_ptr(), cnt.data_ptr(), cap)
+                g2.synchronize()
+                torch.cuda.synchronize()
+                n = int(cnt[0].item())
+                k = kp[0, :n].cpu().numpy()
+                same = n == len(gkp) and np.array_equal(k[:, 0], gkp["x"]) and np.array_equal(k[:, 1], gkp["y"]) and \
+                    np.array_equal(k[:, 3], gkp["angle"]) and np.array_equal(de[0, :n].cpu().numpy(), gdesc)
+                if not same:
+                    bad += 1; print(tag, "DEVICE-RESIDENT RESULT DIFFERS (pad %d, offset %d)" % (pad, off), flush=True)
+            except orbhip.OrbHipError as e:
+                bad += 1; print(tag, "DEVICE-RESIDENT RUN REFUSED:", e, flush=True)
+            try:
+                ckp, cdesc = orbhip.ORBextractor(nf, sf, nl, ini, mn).extract_color(np.repeat(img[:, :, None], 3, axis=2), rgb=bool(index & 1), fetch_pyramid=False)
+                if not (len(ckp) == len(gkp) and np.array_equal(ckp["x"], gkp["x"]) and np.array_equal(ckp["y"], gkp["y"]) and np.array_equal(cdesc, gdesc)):
+                    bad += 1; print(tag, "COLOUR INPUT RESULT DIFFERS", flush=True)
+            except orbhip.OrbHipError as e:
+                bad += 1; print(tag, "COLOUR RUN REFUSED:", e, flush=True)
     print("fuzz_sizes: %d cases, %d refused by both, %d problems" % (args.cases, refused, bad))
     sys.exit(1 if bad else 0)
 
