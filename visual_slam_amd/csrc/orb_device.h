@@ -50,7 +50,7 @@ struct LevelGeom {
     int n_ini; float hx;      // nIni, hX
     int quota;                // mnFeaturesPerLevel[level]
     int node_cap;             // max list length the distribution can reach
-    int qt_words;             // LDS words of k_quadtree before its cell mask: max(20 * node_cap, segments + 1)
+    int qt_words;             // LDS words of k_quadtree before its cell mask: max(18 * node_cap, segments + 1)
     int kp_off;               // offset of this level's slot in the per-frame level-keypoint block
     // output
     float scale;              // mvScaleFactor[level]

@@ -482,7 +482,8 @@ struct QtShared {
     int* kord;            // [M] split order index, or -1
     uint32_t* ordarr;     // [M] node index by split order
     uint32_t* cbase;      // [M] children created before this split node
-    unsigned long long* key64;  // [M] sort keys / best key per node
+    // (the 64-bit sort keys of the size-ordered rounds and the best key per node of the last round live in the
+    // child-count buffer of the round's new list, which nothing else uses while they are needed)
 };
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) { return wave_scan_incl(v); }   // DPP, no LDS traffic
@@ -556,7 +557,7 @@ __device__ __forceinline__ void qt_for_keys(const uint32_t* xy, const S* second,
 template <bool WIDE> struct QtLabel { typedef uint16_t type; };
 template <> struct QtLabel<true> { typedef uint32_t type; };
 
-// SPILL = false: the node arrays live in LDS (every level whose quota fits: 80 bytes per list node).
+// SPILL = false: the node arrays live in LDS (every level whose quota fits: 72 bytes per list node).
 // SPILL = true: the levels whose node arrays do not fit (quotas beyond ~2000 features on one level; the
 // reference has no such limit, src/ORBextractor.cc:539-763) keep them in a global scratch slice per
 // (frame, level) instead; the code is the same, the workgroup's barriers order its own global accesses
@@ -589,7 +590,6 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
     QtShared q;
     {
         uint32_t* p = smem;
-        q.key64 = reinterpret_cast<unsigned long long*>(p); p += 2 * M;
         q.box[0] = p; p += 2 * M; q.box[1] = p; p += 2 * M;
         q.cnt[0] = p; p += M; q.cnt[1] = p; p += M;
         q.cc[0] = p; p += 4 * M; q.cc[1] = p; p += 4 * M;
@@ -709,6 +709,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
     __syncthreads();
 
     int cur = 0;
+    const unsigned long long* best = nullptr;                  // best key per node of the final list
     int mode = 1;               // 1: expand every node with >1 key; 2: expand by size until N
     bool done = false;
     for (int round = 0; round < 64 && !done; round++) {
@@ -721,6 +722,9 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         uint32_t* const box_nxt = cur ? q.box[0] : q.box[1];
         uint32_t* const cnt_cur = cur ? q.cnt[1] : q.cnt[0];
         uint32_t* const cnt_nxt = cur ? q.cnt[0] : q.cnt[1];
+        // 64-bit keys of this round: the new list's child counts are not in use before step D clears them, and
+        // not at all in the round that ends the loop
+        unsigned long long* const key64 = reinterpret_cast<unsigned long long*>(cc_nxt);
         // ---- A. which nodes split, and in which order
         if (tid < 4) s_red[tid] = 0;
         __syncthreads();
@@ -742,18 +746,18 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
             for (int i = tid; i < L; i += QT_THREADS) {
                 const uint32_t c = cnt_cur[i];
                 const bool e = (c & QT_FRESH) && (c & ~QT_FRESH) > 1;
-                q.key64[i] = e ? (((unsigned long long)(c & ~QT_FRESH) << 32) | (0xFFFFFFFFu - (uint32_t)i)) : 0ull;
+                key64[i] = e ? (((unsigned long long)(c & ~QT_FRESH) << 32) | (0xFFFFFFFFu - (uint32_t)i)) : 0ull;
                 ne_l += e;
             }
             if (ne_l) atomicAdd(&s_red[1], ne_l);
             __syncthreads();
             const int nE = (int)s_red[1];
             for (int i = tid; i < L; i += QT_THREADS) {
-                const unsigned long long k = q.key64[i];
+                const unsigned long long k = key64[i];
                 int rank = -1;
                 if (k) {
                     rank = 0;
-                    for (int j = 0; j < L; j++) rank += q.key64[j] > k;
+                    for (int j = 0; j < L; j++) rank += key64[j] > k;
                     q.ordarr[rank] = i;
                 }
                 q.kord[i] = rank;
@@ -869,7 +873,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
             });
         } else {
             // ---- best response per node, first in candidate order on ties (src/ORBextractor.cc:744-760)
-            for (int i = tid; i < Lnew; i += QT_THREADS) q.key64[i] = 0ull;
+            for (int i = tid; i < Lnew; i += QT_THREADS) key64[i] = 0ull;
+            best = key64;
             __syncthreads();
             qt_for_keys(kxy, klab, lab_dead, nkeys, tid, [&](const uint32_t (&exy)[QT_KU], const uint32_t (&elab)[QT_KU], int k0) __attribute__((always_inline)) {
                 uint32_t li[QT_KU], nl[QT_KU], sc[QT_KU];
@@ -897,7 +902,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
                     const uint32_t row_in_cells = umul24((uint32_t)(__mul24(cy, g.ncols) + cx), (uint32_t)g.hcell) +
                                                   (uint32_t)(y - 3 - __mul24(cy, g.hcell));
                     const uint32_t ord = umul24(row_in_cells, (uint32_t)g.wcell) + (uint32_t)(x - 3 - __mul24(cx, g.wcell));
-                    atomicMax(&q.key64[nl[u]], ((unsigned long long)sc[u] << 32) | (0xFFFFFFFFu - ord));
+                    atomicMax(&key64[nl[u]], ((unsigned long long)sc[u] << 32) | (0xFFFFFFFFu - ord));
                 }
             });
         }
@@ -908,7 +913,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
     // ---- output in list order
     LevelKp* out = lvl_kp + (size_t)f * plan->kp_per_frame + g.kp_off;
     for (int i = tid; i < L; i += QT_THREADS) {
-        const unsigned long long b = q.key64[i];
+        const unsigned long long b = best[i];
         const uint32_t ord = 0xFFFFFFFFu - (uint32_t)b;
         const int xin = ord % g.wcell;
         uint32_t t = ord / g.wcell;

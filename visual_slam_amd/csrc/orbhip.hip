@@ -349,9 +349,9 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
         g.seg_off = seg_off; seg_off += (size_t)g.fast_ntiles * 4 * FT_SEGCAP;
         g.segc_off = segc_off; segc_off += g.fast_ntiles * 4;
         g.keys_off = keys_off; keys_off += g.keys_cap;
-        g.qt_words = std::max(20 * g.node_cap, g.fast_ntiles * 4 + 1);
+        g.qt_words = std::max(18 * g.node_cap, g.fast_ntiles * 4 + 1);
         {
-            // node arrays (20 words per node) plus the per-cell bit mask: in LDS when they fit, else in a global slice
+            // node arrays (18 words per node) plus the per-cell bit mask: in LDS when they fit, else in a global slice
             const size_t words = (size_t)g.qt_words + (size_t)(g.ncols * g.nrows + 31) / 32;
             if (words * 4 > e->qt_lds_limit) {
                 P.qt_spill_slot[l] = P.qt_nspill++;
