@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_undistort_grid(const GridKp* __restrict
         if (c >= 0) atomicAdd(&s_cur[c], 1u);
     }
     __syncthreads();
-    const uint32_t total = block_excl_scan(s_cur, GRID_CELLS, s_tmp);
+    const uint32_t total = block_excl_scan<256>(s_cur, GRID_CELLS, s_tmp);
     for (int c = tid; c < GRID_CELLS; c += 256) { s_start[c] = s_cur[c]; gs[c] = (int)s_cur[c]; }
     if (tid == 0) { s_start[GRID_CELLS] = total; gs[GRID_CELLS] = (int)total; }
     __syncthreads();

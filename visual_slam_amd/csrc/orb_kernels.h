@@ -469,9 +469,10 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 // column, raster), encoded as `ord`. Equal-size nodes in the final expansion rounds are taken in
 // reverse creation order (the reference compares heap addresses there).
 // ------------------------------------------------------------------------------------------------
-#ifndef QT_THREADS
-#define QT_THREADS 256
-#endif
+// Threads per workgroup (QT_T): 256 where a level holds thousands of keys (the loops over keys scale with the threads),
+// 128 where the lists are short (the node steps, a dozen barriers and three scans per round, cost more with every wave
+// that joins them): 1080p / 2000 features 1.13 / 0.86 / 0.90 ms per 1024 frames at 128 / 256 / 512 threads, VGA / 1000
+// features 0.20 / 0.24 / 0.40. The host picks by the quota of level 0.
 #define QT_FRESH 0x80000000u
 
 struct QtShared {
@@ -489,9 +490,10 @@ struct QtShared {
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) { return wave_scan_incl(v); }   // DPP, no LDS traffic
 
 // In-place exclusive scan of a[0..n) by the whole workgroup; returns the total.
+template <int QT_T>
 __device__ uint32_t block_excl_scan(uint32_t* a, int n, uint32_t* s_tmp) {
     const int tid = threadIdx.x;
-    const int chunk = (n + QT_THREADS - 1) / QT_THREADS;
+    const int chunk = (n + QT_T - 1) / QT_T;
     const int lo = min(tid * chunk, n), hi = min(lo + chunk, n);
     uint32_t s = 0;
     for (int i = lo; i < hi; i++) s += a[i];
@@ -500,7 +502,7 @@ __device__ uint32_t block_excl_scan(uint32_t* a, int n, uint32_t* s_tmp) {
     __syncthreads();
     uint32_t off = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < QT_THREADS / 64; w++) {
+    for (int w = 0; w < QT_T / 64; w++) {
         if (w < (tid >> 6)) off += s_tmp[w];
         total += s_tmp[w];
     }
@@ -522,7 +524,7 @@ __device__ __forceinline__ int qt_quadrant(uint32_t bx, uint32_t by, int x, int 
 // levels that keep them in global memory. A round then moves 8 bytes per key (position read, label read
 // and written), which is what bounds the kernel on large frames.
 //
-// Runs `body(a, b, k0)` over all keys of a thread (key k0 + u * QT_THREADS: its position in a[u], its
+// Runs `body(a, b, k0)` over all keys of a thread (key k0 + u * QT_T: its position in a[u], its
 // entry of the second array - label or score - in b[u]; slots past the end hold a dropped key at the
 // window origin), QT_KU keys per trip. The keys of the next trip are requested before the body runs:
 // the loops over keys are bound by memory latency.
@@ -530,21 +532,21 @@ __device__ __forceinline__ int qt_quadrant(uint32_t bx, uint32_t by, int x, int 
 #define QT_KU 4   // (8 keys per trip need 104 registers per lane; 4 need 68, and the workgroups that fit beside each other
                   // hide more latency than the longer trips did: VGA-sized frames 30 % faster, 1080p unchanged)
 #endif
-template <typename S, typename F>
+template <int QT_T, typename S, typename F>
 __device__ __forceinline__ void qt_for_keys(const uint32_t* xy, const S* second, uint32_t second_dead, int nkeys, int tid, F&& body) {
     const uint32_t xy_dead = 3u | (3u << 16);
     uint32_t a[QT_KU], b[QT_KU];
 #pragma unroll
     for (int u = 0; u < QT_KU; u++) {
-        const int k = tid + u * QT_THREADS;
+        const int k = tid + u * QT_T;
         a[u] = xy_dead; b[u] = second_dead;
         if (k < nkeys) { a[u] = xy[k]; b[u] = second[k]; }
     }
-    for (int k0 = tid; k0 < nkeys; k0 += QT_KU * QT_THREADS) {
+    for (int k0 = tid; k0 < nkeys; k0 += QT_KU * QT_T) {
         uint32_t na[QT_KU], nb[QT_KU];
 #pragma unroll
         for (int u = 0; u < QT_KU; u++) {
-            const int k = k0 + (QT_KU + u) * QT_THREADS;
+            const int k = k0 + (QT_KU + u) * QT_T;
             na[u] = xy_dead; nb[u] = second_dead;
             if (k < nkeys) { na[u] = xy[k]; nb[u] = second[k]; }
         }
@@ -562,8 +564,8 @@ template <> struct QtLabel<true> { typedef uint32_t type; };
 // reference has no such limit, src/ORBextractor.cc:539-763) keep them in a global scratch slice per
 // (frame, level) instead; the code is the same, the workgroup's barriers order its own global accesses
 // (all its waves share one CU and its cache). Each variant returns at once on the other's levels.
-template <bool SPILL>
-__global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restrict__ plan,
+template <bool SPILL, int QT_T>
+__global__ __launch_bounds__(QT_T) void k_quadtree(const PlanDev* __restrict__ plan,
                                                          const uint2* __restrict__ seg,
                                                          const int* __restrict__ seg_count,
                                                          uint32_t* __restrict__ keys_xy_all, uint8_t* __restrict__ keys_score_all,
@@ -574,7 +576,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
                                                          int* __restrict__ status,
                                                          uint32_t* __restrict__ spill, unsigned long long spill_stride) {
     extern __shared__ __align__(16) uint32_t smem_lds[];
-    __shared__ uint32_t s_tmp[QT_THREADS / 64];
+    __shared__ uint32_t s_tmp[QT_T / 64];
     __shared__ uint32_t s_red[4];
     __shared__ int s_nkeys;
     const int tid = threadIdx.x;
@@ -612,15 +614,15 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
     // at the initial threshold (src/ORBextractor.cc:808-816: a cell is re-run at minThFAST only when
     // it found nothing at iniThFAST)
     const int ncells = g.ncols * g.nrows;
-    for (int i = tid; i < (ncells + 31) / 32; i += QT_THREADS) cellbits[i] = 0;
+    for (int i = tid; i < (ncells + 31) / 32; i += QT_T) cellbits[i] = 0;
     const int nseg = g.fast_ntiles * 4;
     uint32_t* segbase = smem;                      // [nseg + 1], aliases the node arrays (not in use yet)
     {
         // step 1: segment sizes -> exclusive prefix sums = positions in `keys`
         const int* sc = seg_count + (size_t)f * plan->segc_per_frame + g.segc_off;
-        for (int sidx = tid; sidx < nseg; sidx += QT_THREADS) segbase[sidx] = (uint32_t)max(sc[sidx], 0);
+        for (int sidx = tid; sidx < nseg; sidx += QT_T) segbase[sidx] = (uint32_t)max(sc[sidx], 0);
         __syncthreads();
-        const uint32_t total = block_excl_scan(segbase, nseg, s_tmp);
+        const uint32_t total = block_excl_scan<QT_T>(segbase, nseg, s_tmp);
         if (tid == 0) { segbase[nseg] = total; s_nkeys = (int)total; }
         __syncthreads();
         // step 2: one thread per key position p: binary search for its segment (the last one with
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         const uint2* sbase = seg + (size_t)f * plan->seg_per_frame + g.seg_off;
         const int ncopy = min((int)total, g.keys_cap);
         const int nsteps = nseg > 1 ? 32 - __clz(nseg - 1) : 0;
-        for (int p0 = tid; p0 < ncopy; p0 += QT_KU * QT_THREADS) {
+        for (int p0 = tid; p0 < ncopy; p0 += QT_KU * QT_T) {
             int lo[QT_KU], hi[QT_KU];
 #pragma unroll
             for (int u = 0; u < QT_KU; u++) { lo[u] = 0; hi[u] = nseg; }
@@ -637,18 +639,18 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
 #pragma unroll
                 for (int u = 0; u < QT_KU; u++) {
                     const int mid = (lo[u] + hi[u]) >> 1;
-                    if ((int)segbase[mid] <= min(p0 + u * QT_THREADS, ncopy - 1)) lo[u] = mid; else hi[u] = mid;
+                    if ((int)segbase[mid] <= min(p0 + u * QT_T, ncopy - 1)) lo[u] = mid; else hi[u] = mid;
                 }
             }
             uint2 e[QT_KU];
 #pragma unroll
             for (int u = 0; u < QT_KU; u++) {
-                const int p = min(p0 + u * QT_THREADS, ncopy - 1);
+                const int p = min(p0 + u * QT_T, ncopy - 1);
                 e[u] = sbase[(size_t)lo[u] * FT_SEGCAP + (p - (int)segbase[lo[u]])];
             }
 #pragma unroll
             for (int u = 0; u < QT_KU; u++) {
-                const int p = p0 + u * QT_THREADS;
+                const int p = p0 + u * QT_T;
                 if (p >= ncopy) continue;
                 kxy[p] = e[u].x;
                 ksc[p] = (uint8_t)e[u].y;
@@ -670,7 +672,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
 
     // ---- roots (src/ORBextractor.cc:543-585)
     int L = g.n_ini;            // length of the node array (round 0 may contain empty roots)
-    for (int i = tid; i < M; i += QT_THREADS) {
+    for (int i = tid; i < M; i += QT_T) {
         if (i < L) {
             const int x0 = (int)(g.hx * (float)i), x1 = (int)(g.hx * (float)(i + 1));
             q.box[0][2 * i] = (uint32_t)x0 | ((uint32_t)x1 << 16);
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         q.cc[0][4 * i] = q.cc[0][4 * i + 1] = q.cc[0][4 * i + 2] = q.cc[0][4 * i + 3] = 0;
     }
     __syncthreads();
-    qt_for_keys(kxy, ksc, 0u, nkeys, tid, [&](const uint32_t (&exy)[QT_KU], const uint32_t (&esc)[QT_KU], int k0) __attribute__((always_inline)) {
+    qt_for_keys<QT_T>(kxy, ksc, 0u, nkeys, tid, [&](const uint32_t (&exy)[QT_KU], const uint32_t (&esc)[QT_KU], int k0) __attribute__((always_inline)) {
         int x[QT_KU], y[QT_KU], s[QT_KU], cell[QT_KU], root[QT_KU];
         uint32_t cb[QT_KU], b0[QT_KU], b1[QT_KU];
 #pragma unroll
@@ -692,7 +694,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         }
 #pragma unroll
         for (int u = 0; u < QT_KU; u++) {
-            const int k = k0 + u * QT_THREADS;
+            const int k = k0 + u * QT_T;
             if (k >= nkeys) continue;
             uint32_t lab = lab_dead;
             if (s[u] >= ini_th || ((cb[u] >> (cell[u] & 31)) & 1) == 0) {
@@ -704,7 +706,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         }
     });
     __syncthreads();
-    for (int i = tid; i < L; i += QT_THREADS)
+    for (int i = tid; i < L; i += QT_T)
         q.cnt[0][i] = (q.cc[0][4 * i] + q.cc[0][4 * i + 1] + q.cc[0][4 * i + 2] + q.cc[0][4 * i + 3]) | QT_FRESH;
     __syncthreads();
 
@@ -729,21 +731,21 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         if (tid < 4) s_red[tid] = 0;
         __syncthreads();
         uint32_t prev_size_l = 0;
-        for (int i = tid; i < L; i += QT_THREADS) prev_size_l += (cnt_cur[i] & ~QT_FRESH) > 0;
+        for (int i = tid; i < L; i += QT_T) prev_size_l += (cnt_cur[i] & ~QT_FRESH) > 0;
         if (prev_size_l) atomicAdd(&s_red[0], prev_size_l);
         int nsplit;
         if (mode == 1) {
-            for (int i = tid; i < L; i += QT_THREADS) q.ordarr[i] = (cnt_cur[i] & ~QT_FRESH) > 1;
+            for (int i = tid; i < L; i += QT_T) q.ordarr[i] = (cnt_cur[i] & ~QT_FRESH) > 1;
             __syncthreads();
-            nsplit = (int)block_excl_scan(q.ordarr, L, s_tmp);
-            for (int i = tid; i < L; i += QT_THREADS)
+            nsplit = (int)block_excl_scan<QT_T>(q.ordarr, L, s_tmp);
+            for (int i = tid; i < L; i += QT_T)
                 q.kord[i] = (cnt_cur[i] & ~QT_FRESH) > 1 ? (int)q.ordarr[i] : -1;
             __syncthreads();
         } else {
             // candidates: nodes created in the previous round that hold more than one key, largest
             // first; equal sizes: latest created first (= smaller list position)
             uint32_t ne_l = 0;
-            for (int i = tid; i < L; i += QT_THREADS) {
+            for (int i = tid; i < L; i += QT_T) {
                 const uint32_t c = cnt_cur[i];
                 const bool e = (c & QT_FRESH) && (c & ~QT_FRESH) > 1;
                 key64[i] = e ? (((unsigned long long)(c & ~QT_FRESH) << 32) | (0xFFFFFFFFu - (uint32_t)i)) : 0ull;
@@ -752,7 +754,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
             if (ne_l) atomicAdd(&s_red[1], ne_l);
             __syncthreads();
             const int nE = (int)s_red[1];
-            for (int i = tid; i < L; i += QT_THREADS) {
+            for (int i = tid; i < L; i += QT_T) {
                 const unsigned long long k = key64[i];
                 int rank = -1;
                 if (k) {
@@ -764,17 +766,17 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
             }
             __syncthreads();
             // growth of the list when the first r+1 candidates are split
-            for (int r = tid; r < nE; r += QT_THREADS) {
+            for (int r = tid; r < nE; r += QT_T) {
                 const int i = q.ordarr[r];
                 const uint32_t* c = &cc_cur[4 * i];
                 q.cbase[r] = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0) - 1;
             }
             __syncthreads();
-            block_excl_scan(q.cbase, nE, s_tmp);
+            block_excl_scan<QT_T>(q.cbase, nE, s_tmp);
             // inclusive value for r = exclusive[r] + own; count r with size still below N
             uint32_t below_l = 0;
             const int size0 = (int)s_red[0];
-            for (int r = tid; r < nE; r += QT_THREADS) {
+            for (int r = tid; r < nE; r += QT_T) {
                 const int i = q.ordarr[r];
                 const uint32_t* c = &cc_cur[4 * i];
                 const int own = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0) - 1;
@@ -783,13 +785,13 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
             if (below_l) atomicAdd(&s_red[2], below_l);
             __syncthreads();
             nsplit = min((int)s_red[2] + 1, nE);
-            for (int i = tid; i < L; i += QT_THREADS)
+            for (int i = tid; i < L; i += QT_T)
                 if (q.kord[i] >= nsplit) q.kord[i] = -1;
             __syncthreads();
         }
         const int prev_size = (int)s_red[0];
         // ---- B. children created before each split node (creation order = split order, n1..n4)
-        for (int i = tid; i < L; i += QT_THREADS) {
+        for (int i = tid; i < L; i += QT_T) {
             const int k = q.kord[i];
             if (k >= 0) {
                 q.ordarr[k] = i;
@@ -798,16 +800,16 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
             }
         }
         __syncthreads();
-        const int C = (int)block_excl_scan(q.cbase, nsplit, s_tmp);
+        const int C = (int)block_excl_scan<QT_T>(q.cbase, nsplit, s_tmp);
         // ---- C. unsplit, non-empty nodes keep their relative order behind the children
-        for (int i = tid; i < L; i += QT_THREADS)
+        for (int i = tid; i < L; i += QT_T)
             q.surv[i] = (q.kord[i] < 0 && (cnt_cur[i] & ~QT_FRESH) > 0) ? 1u : 0u;
         __syncthreads();
-        const int S = (int)block_excl_scan(q.surv, L, s_tmp);
+        const int S = (int)block_excl_scan<QT_T>(q.surv, L, s_tmp);
         const int Lnew = C + S;
         // ---- D. build the new list
         uint32_t expand_l = 0;
-        for (int i = tid; i < L; i += QT_THREADS) {
+        for (int i = tid; i < L; i += QT_T) {
             const uint32_t c = cnt_cur[i] & ~QT_FRESH;
             const int k = q.kord[i];
             if (k >= 0) {
@@ -837,7 +839,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
             }
         }
         if (expand_l) atomicAdd(&s_red[3], expand_l);
-        for (int i = tid; i < 4 * Lnew; i += QT_THREADS) cc_nxt[i] = 0;
+        for (int i = tid; i < 4 * Lnew; i += QT_T) cc_nxt[i] = 0;
         __syncthreads();
         const int to_expand = (int)s_red[3];
         // ---- finish test (src/ORBextractor.cc:669-673, 734-735)
@@ -845,7 +847,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
         else if (mode == 1 && Lnew + 3 * to_expand > N) mode = 2;
         // ---- E. keys follow their nodes
         if (!done) {
-            qt_for_keys(kxy, klab, lab_dead, nkeys, tid, [&](const uint32_t (&exy)[QT_KU], const uint32_t (&elab)[QT_KU], int k0) __attribute__((always_inline)) {
+            qt_for_keys<QT_T>(kxy, klab, lab_dead, nkeys, tid, [&](const uint32_t (&exy)[QT_KU], const uint32_t (&elab)[QT_KU], int k0) __attribute__((always_inline)) {
                 uint32_t li[QT_KU], nl[QT_KU], bx[QT_KU], by[QT_KU];
                 int ko[QT_KU];
                 bool alive[QT_KU];
@@ -868,15 +870,15 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
                     if (!alive[u]) continue;
                     const uint32_t nq = qt_quadrant(bx[u], by[u], exy[u] & 0xFFFF, exy[u] >> 16);
                     atomicAdd(&cc_nxt[4 * nl[u] + nq], 1u);
-                    klab[k0 + u * QT_THREADS] = (Lab)(nq | (nl[u] << 2));
+                    klab[k0 + u * QT_T] = (Lab)(nq | (nl[u] << 2));
                 }
             });
         } else {
             // ---- best response per node, first in candidate order on ties (src/ORBextractor.cc:744-760)
-            for (int i = tid; i < Lnew; i += QT_THREADS) key64[i] = 0ull;
+            for (int i = tid; i < Lnew; i += QT_T) key64[i] = 0ull;
             best = key64;
             __syncthreads();
-            qt_for_keys(kxy, klab, lab_dead, nkeys, tid, [&](const uint32_t (&exy)[QT_KU], const uint32_t (&elab)[QT_KU], int k0) __attribute__((always_inline)) {
+            qt_for_keys<QT_T>(kxy, klab, lab_dead, nkeys, tid, [&](const uint32_t (&exy)[QT_KU], const uint32_t (&elab)[QT_KU], int k0) __attribute__((always_inline)) {
                 uint32_t li[QT_KU], nl[QT_KU], sc[QT_KU];
                 int ko[QT_KU];
                 bool alive[QT_KU];
@@ -885,7 +887,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
                     alive[u] = elab[u] != lab_dead;            // (the slots past the end are dropped keys)
                     li[u] = alive[u] ? elab[u] >> 2 : 0u;
                     ko[u] = q.kord[li[u]];
-                    sc[u] = alive[u] ? (uint32_t)ksc[k0 + u * QT_THREADS] : 0u;
+                    sc[u] = alive[u] ? (uint32_t)ksc[k0 + u * QT_T] : 0u;
                 }
 #pragma unroll
                 for (int u = 0; u < QT_KU; u++) {
@@ -912,7 +914,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const PlanDev* __restri
     }
     // ---- output in list order
     LevelKp* out = lvl_kp + (size_t)f * plan->kp_per_frame + g.kp_off;
-    for (int i = tid; i < L; i += QT_THREADS) {
+    for (int i = tid; i < L; i += QT_T) {
         const unsigned long long b = best[i];
         const uint32_t ord = 0xFFFFFFFFu - (uint32_t)b;
         const int xin = ord % g.wcell;
@@ -1205,7 +1207,6 @@ __global__ __launch_bounds__(256) void k_describe(const PlanDev* __restrict__ pl
     sincos_rounded(ang_rad, &a, &b);
     const int ties_even = plan->blur_ties_even;
     const v2f_t ab = {a, b}, nba = {-b, a};
-    const uint16_t* hp_top = hp + 19 * DS_HP_P + 19;          // row sums of (row offset -3, column offset 0) from the keypoint
     // tap pairs for the dot products over the eight sums of a window (rows -3 .. +4; the last one gets weight 0)
     const v2us_t w01 = {(unsigned short)t3, (unsigned short)t2}, w23 = {(unsigned short)t1, (unsigned short)t0};
     const v2us_t w45 = {(unsigned short)t1, (unsigned short)t2}, w67 = {(unsigned short)t3, 0};

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_stereo_prep(const PlanDev* __restrict__
     };
     for (int i = tid; i < nr; i += 256) { int bin; record(i, bin); atomicAdd(&s_hist[bin], 1u); }
     __syncthreads();
-    const uint32_t total = block_excl_scan(s_hist, nbins, s_tmp);
+    const uint32_t total = block_excl_scan<256>(s_hist, nbins, s_tmp);
     if (tid == 0) s_hist[nbins] = total;
     __syncthreads();
     int* bs = binstart + (size_t)f * (nbins + 1);

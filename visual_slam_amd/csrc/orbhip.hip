@@ -61,6 +61,10 @@ struct Workspace {
     bool l0_in_plane = true;
 };
 const int kLanes = 4;
+// Level-0 quotas up to this run the quadtree with 128 threads per workgroup: 640 x 480 / 1000 features (quota 217) 0.193
+// against 0.239 ms per 1024 frames at 256 threads, 752 x 480 / 1200 (261) 0.216 against 0.243; 1241 x 376 / 2000 (434) 0.393
+// against 0.336, 1080p / 2000 1.13 against 0.82
+const int kQtSmallQuota = 300;
 const int kMinLaneFrames = 16;     // batches below twice this run as one pass on the caller's stream
 
 } // namespace
@@ -113,6 +117,7 @@ struct orbhip_extractor {
     RsTab* d_tabs = nullptr;
     Workspace ws[kLanes];
     int plan_lanes = 0;            // workspaces allocated for the current plan
+    int qt_threads = 0;            // ORBHIP_QT_THREADS=128|256: the quadtree's workgroup size whatever the frame size (0: by frame size)
     bool debug_skip_describe = false;   // ORBHIP_DEBUG_SKIP_DESCRIBE=1: stop after the quadtree (orbhip_debug_level_keypoints shows its output)
     bool debug_sync = false;       // ORBHIP_DEBUG_SYNC=1: wait after every group of launches and name the one that failed
     int max_lanes = 1;             // ORBHIP_LANES=2..4: that many passes of a large batch in flight (a few % more throughput)
@@ -440,7 +445,10 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     e->plan_lanes = lanes;
     if (e->qt_lds > 64 * 1024)
-        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->qt_lds));
+    {
+        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->qt_lds));
+        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree<false, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->qt_lds));
+    }
     e->plan_w = w; e->plan_h = h; e->plan_frames = frames;
     return ORBHIP_OK;
 }
@@ -591,14 +599,20 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
     if (int rc = debug_sync_point(e, s, "k_fast")) return rc;
     {
         SpanGuard t(e, s, KC_QUADTREE);
-        if (P.qt_nspill < nl)
-            hipLaunchKernelGGL(k_quadtree<false>, dim3(frames, nl), dim3(QT_THREADS), e->qt_lds, s,
+        // 128 threads per (frame, level) where the lists stay short, 256 otherwise (see k_quadtree)
+        const bool small = e->qt_threads ? e->qt_threads == 128 : P.lv[0].quota <= kQtSmallQuota;
+        if (P.qt_nspill < nl) {
+            auto* fn = small ? k_quadtree<false, 128> : k_quadtree<false, 256>;
+            hipLaunchKernelGGL(fn, dim3(frames, nl), dim3(small ? 128 : 256), e->qt_lds, s,
                                e->d_plan, W.d_seg, W.d_seg_count, W.d_keys_xy, W.d_keys_score, W.d_keys_label, W.d_key_count, W.d_lvl_kp, W.d_lvl_cnt,
                                e->d_status, static_cast<uint32_t*>(nullptr), 0ull);
-        if (P.qt_nspill)
-            hipLaunchKernelGGL(k_quadtree<true>, dim3(frames, nl), dim3(QT_THREADS), 0, s,
+        }
+        if (P.qt_nspill) {
+            auto* fn = small ? k_quadtree<true, 128> : k_quadtree<true, 256>;
+            hipLaunchKernelGGL(fn, dim3(frames, nl), dim3(small ? 128 : 256), 0, s,
                                e->d_plan, W.d_seg, W.d_seg_count, W.d_keys_xy, W.d_keys_score, W.d_keys_label, W.d_key_count, W.d_lvl_kp, W.d_lvl_cnt,
                                e->d_status, W.d_qt_spill, (unsigned long long)e->qt_spill_words);
+        }
     }
     if (int rc = debug_sync_point(e, s, "k_quadtree")) return rc;
     if (e->debug_skip_describe) HIP_TRY(e, hipMemsetAsync(d_counts + frame0, 0, (size_t)frames * sizeof(int), s));
@@ -710,6 +724,7 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
              hipEventCreateWithFlags(&w.done, hipEventDisableTiming) == hipSuccess;
     if (!ok) { orbhip_destroy(e); return ORBHIP_ERR_HIP; }
     if (const char* v = std::getenv("ORBHIP_DEBUG_SKIP_DESCRIBE")) e->debug_skip_describe = std::atoi(v) != 0;
+    if (const char* v = std::getenv("ORBHIP_QT_THREADS")) e->qt_threads = std::atoi(v) == 128 ? 128 : std::atoi(v) == 256 ? 256 : 0;
     if (const char* v = std::getenv("ORBHIP_DEBUG_SYNC")) e->debug_sync = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_LANES")) e->max_lanes = std::min(kLanes, std::max(1, std::atoi(v)));
     if (const char* v = std::getenv("ORBHIP_OVERLAP")) e->overlap = std::atoi(v) != 0;
