@@ -65,6 +65,7 @@ const int kLanes = 4;
 // against 0.239 ms per 1024 frames at 256 threads, 752 x 480 / 1200 (261) 0.216 against 0.243; 1241 x 376 / 2000 (434) 0.393
 // against 0.336, 1080p / 2000 1.13 against 0.82
 const int kQtSmallQuota = 300;
+const int kQtLatencyGroups = 256;   // (frames x levels) up to this: a pass that cannot fill the chip
 const int kMinLaneFrames = 16;     // batches below twice this run as one pass on the caller's stream
 
 } // namespace
@@ -599,17 +600,21 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
     if (int rc = debug_sync_point(e, s, "k_fast")) return rc;
     {
         SpanGuard t(e, s, KC_QUADTREE);
-        // 128 threads per (frame, level) where the lists stay short, 256 otherwise (see k_quadtree)
-        const bool small = e->qt_threads ? e->qt_threads == 128 : P.lv[0].quota <= kQtSmallQuota;
+        // Threads per (frame, level): 128 where the lists stay short and the pass fills the chip, 256 otherwise (a pass of
+        // a few frames leaves most of the chip idle, and what counts then is the time of one workgroup: one 1080p frame
+        // host to host 0.43 ms with 128 threads, 0.38 with 256, 0.37 with 1024). See k_quadtree.
+        const int qt = e->qt_threads ? e->qt_threads : (frames * nl > kQtLatencyGroups && P.lv[0].quota <= kQtSmallQuota) ? 128 : 256;
+        typedef void (*QtFn)(const PlanDev*, const uint2*, const int*, uint32_t*, uint8_t*, uint32_t*, int*, LevelKp*, int*, int*, uint32_t*,
+                             unsigned long long);
         if (P.qt_nspill < nl) {
-            auto* fn = small ? k_quadtree<false, 128> : k_quadtree<false, 256>;
-            hipLaunchKernelGGL(fn, dim3(frames, nl), dim3(small ? 128 : 256), e->qt_lds, s,
+            QtFn fn = qt == 128 ? k_quadtree<false, 128> : k_quadtree<false, 256>;
+            hipLaunchKernelGGL(fn, dim3(frames, nl), dim3(qt), e->qt_lds, s,
                                e->d_plan, W.d_seg, W.d_seg_count, W.d_keys_xy, W.d_keys_score, W.d_keys_label, W.d_key_count, W.d_lvl_kp, W.d_lvl_cnt,
                                e->d_status, static_cast<uint32_t*>(nullptr), 0ull);
         }
         if (P.qt_nspill) {
-            auto* fn = small ? k_quadtree<true, 128> : k_quadtree<true, 256>;
-            hipLaunchKernelGGL(fn, dim3(frames, nl), dim3(small ? 128 : 256), 0, s,
+            QtFn fn = qt == 128 ? k_quadtree<true, 128> : k_quadtree<true, 256>;
+            hipLaunchKernelGGL(fn, dim3(frames, nl), dim3(qt), 0, s,
                                e->d_plan, W.d_seg, W.d_seg_count, W.d_keys_xy, W.d_keys_score, W.d_keys_label, W.d_key_count, W.d_lvl_kp, W.d_lvl_cnt,
                                e->d_status, W.d_qt_spill, (unsigned long long)e->qt_spill_words);
         }
@@ -724,7 +729,7 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
              hipEventCreateWithFlags(&w.done, hipEventDisableTiming) == hipSuccess;
     if (!ok) { orbhip_destroy(e); return ORBHIP_ERR_HIP; }
     if (const char* v = std::getenv("ORBHIP_DEBUG_SKIP_DESCRIBE")) e->debug_skip_describe = std::atoi(v) != 0;
-    if (const char* v = std::getenv("ORBHIP_QT_THREADS")) e->qt_threads = std::atoi(v) == 128 ? 128 : std::atoi(v) == 256 ? 256 : 0;
+    if (const char* v = std::getenv("ORBHIP_QT_THREADS")) { const int t = std::atoi(v); e->qt_threads = (t == 128 || t == 256) ? t : 0; }
     if (const char* v = std::getenv("ORBHIP_DEBUG_SYNC")) e->debug_sync = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_LANES")) e->max_lanes = std::min(kLanes, std::max(1, std::atoi(v)));
     if (const char* v = std::getenv("ORBHIP_OVERLAP")) e->overlap = std::atoi(v) != 0;
