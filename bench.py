@@ -317,10 +317,18 @@ def main():
         # at the 2.4 GHz peak clock.
         valu, valu_src = profiled_valu(kname, frames_per_launch) if profiled else (None, None)
         if valu:
-            peak_rate = 256 * 4 / VALU_CYCLES_PER_INST * 2.4e9
+            # Priced per instruction class it cannot pass 1: every wave64 instruction needs at least the 4 cycles of a
+            # 16-lane SIMD except the plain two-operand 32-bit / 16-bit class, which the calibration measured at 2.2.
+            # The counters give no split by class, so the ceiling used is the architectural one, 4 cycles for every
+            # instruction ("frac": an upper estimate of the busy share when part of the stream is in the fast class);
+            # "frac_at_calibrated_4.25" is the same count against the measured rate of the slow class, and can pass 1
+            # by exactly the share of fast-class instructions.
+            peak_arch = 256 * 4 / 4.0 * 2.4e9
+            peak_cal = 256 * 4 / VALU_CYCLES_PER_INST * 2.4e9
             roofline["valu"] = {"wave_insts_per_launch": valu, "source": valu_src, "achieved_insts_per_s": round(valu / k_avg_s, 1),
+                                "peak_insts_per_s": peak_arch, "cycles_per_inst_peak": 4.0, "frac": round(valu / k_avg_s / peak_arch, 4),
                                 "cycles_per_inst_calibrated": VALU_CYCLES_PER_INST, "calibration": "profiles/r02_valu_calib.txt",
-                                "peak_insts_per_s": peak_rate, "frac": round(valu / k_avg_s / peak_rate, 4)}
+                                "frac_at_calibrated_4.25": round(valu / k_avg_s / peak_cal, 4)}
         # with several passes in flight (ORBHIP_LANES > 1) also time the same kernels one at a time (a
         # second handle limited to one pass, two untimed steps): a kernel with the GPU to itself
         if lanes > 1:
@@ -354,7 +362,10 @@ def main():
         if args.cpu_frames > 0 and world == 1:           # the CPU baseline is timed at N = 1 only
             from oracle import orb_oracle   # checker / baseline only, never on the measured GPU path
             from visual_slam_amd import synth
-            nthreads = min(16, os.cpu_count() or 1)
+            # one oracle instance per host core this process may run on (the affinity mask; os.cpu_count() would
+            # name every CPU of the machine, most of which a one-GPU share of the box does not own)
+            host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            nthreads = max(1, host_cores)
             if args.stereo:
                 # pairs dealt to worker threads (ctypes releases the GIL), each with its own two oracle instances
                 from concurrent.futures import ThreadPoolExecutor
@@ -373,23 +384,54 @@ def main():
                 with ThreadPoolExecutor(nthreads) as pool:
                     list(pool.map(work, range(nthreads)))
                 secs = time.perf_counter() - t1
-                cpu = {"value": round(npairs / secs, 2), "unit": "pairs/s", "cores": nthreads, "kind": "port",
+                cpu = {"value": round(npairs / secs, 2), "unit": "pairs/s", "cores": nthreads, "threads": nthreads, "host_cores": host_cores,
+                       "machine_cpus": os.cpu_count(), "kind": "port",
                        "sample": "the first %d of the %d %s pairs of %s the GPU step extracts, two oracle instances per thread" % (npairs, B, args.kind, args.workload)}
             else:
                 ncpu = min(args.cpu_frames, B)
                 sample = frames[:ncpu].cpu().numpy()     # the first frames of the very batch the GPU steps extract
                 secs, ccounts = orb_oracle.extract_batch_mt((nfeat, scale, levels, ini_th, min_th), sample, nthreads)
                 same = bool(np.array_equal(ccounts, counts[:ncpu]))
-                cpu = {"value": round(ncpu / secs, 2), "unit": "frames/s", "cores": nthreads, "kind": "port",
+                cpu = {"value": round(ncpu / secs, 2), "unit": "frames/s", "cores": nthreads, "threads": nthreads, "host_cores": host_cores,
+                       "machine_cpus": os.cpu_count(), "kind": "port",
                        "sample": "the first %d of the %d %s frames of %s the GPU step extracts, one oracle instance per thread" % (ncpu, B, args.kind, args.workload),
                        "keypoint_counts_equal_gpu": same}
         extra = {}
         if args.host_fed:
-            host = frames[:min(B, 64)].cpu().numpy()
-            ex.extract_batch(host)
+            # PCIe-inclusive rate of the host entry point (images in host memory in, results in host memory out): never
+            # `value`. Pageable images are packed into page-locked staging by the library's host threads, page-locked
+            # ones are copied from where they lie. Beside it the host-to-device copy bandwidth measured here.
+            nh = min(B, 512)
+            pageable = frames[:nh].cpu()
+            pinned = pageable.pin_memory()
+            dst = torch.empty_like(frames[:nh])
+            dst.copy_(pinned, non_blocking=True)
+            torch.cuda.synchronize()
             t1 = time.perf_counter()
-            ex.extract_batch(host)
-            extra["host_fed_frames_per_s"] = round(len(host) / (time.perf_counter() - t1), 1)
+            for _ in range(3):
+                dst.copy_(pinned, non_blocking=True)
+            torch.cuda.synchronize()
+            h2d_gbs = 3 * pinned.numel() / (time.perf_counter() - t1) / 1e9
+            h_kp = np.zeros((nh, cap), orbhip.KP_DTYPE)
+            h_desc = np.zeros((nh, cap, 32), np.uint8)
+            h_cnt = np.zeros(nh, np.int32)
+            hf = {"frames": nh, "h2d_copy_GBs": round(h2d_gbs, 1), "h2d_ceiling_frames_per_s": round(h2d_gbs * 1e9 / (w * h), 1)}
+            for name, t in (("pageable", pageable), ("pinned", pinned)):
+                arr = t.numpy()
+                best = 0.0
+                for rep in range(3):                       # the first call builds the plan and the staging buffers
+                    t1 = time.perf_counter()
+                    rc = orbhip.lib().orbhip_extract_batch(ex._h, arr.ctypes.data, nh, w, h, w, w * h, h_kp.ctypes.data,
+                                                           h_desc.ctypes.data, h_cnt.ctypes.data, cap)
+                    secs = time.perf_counter() - t1
+                    if rc:
+                        raise orbhip.OrbHipError(rc, orbhip.lib().orbhip_last_error(ex._h).decode())
+                    if rep:
+                        best = max(best, nh / secs)
+                hf[name] = {"frames_per_s": round(best, 1), "image_GBs": round(best * w * h / 1e9, 2),
+                            "frac_of_h2d_copy": round(best * w * h / 1e9 / h2d_gbs, 3),
+                            "counts_equal_device_resident": bool(np.array_equal(h_cnt, counts[:nh]))}
+            extra["host_fed"] = hf
         line = {
             "metric": ("ORB extract + stereo match pairs/s" if args.stereo else
                        "ORB extract frames/s (1080p, 2k feats)" if args.workload == "C4_1080p_2000f" else "ORB extract frames/s"),
@@ -398,6 +440,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": args.workload, "image": [w, h], "nfeatures": nfeat, "levels": levels, "scale": scale,
                        "fast_th": [ini_th, min_th], "frames_per_gpu_per_step": B, "frames_per_step": job_units, "distribution": args.kind,
+                       "base_frames": min(16, B), "expanded_by": "circular shifts of the base frames (37 rows, 101 columns per repeat)",
                        "inputs": "device-resident" + (", %d-channel BGR" % args.color if args.color else "") + (", rectified by remap" if args.rectify else ""), "pyramid_copied_back": False, "blur_variant": "legacy",
                        "mean_keypoints_per_frame": round(n_out, 1), "sharding": "frames, no collective",
                        **({"stereo": True, "mean_matches_per_pair": round(float(d_nm.float().mean().item()), 1)} if args.stereo else {})},

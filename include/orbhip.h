@@ -9,7 +9,9 @@
  * Conventions: plain pointers and sizes, int status codes (0 = ORBHIP_OK, negative = error),
  * no exceptions cross the ABI. A handle owns one HIP stream and all device workspaces; distinct
  * handles may be used concurrently from different threads (the reference runs two extractor
- * instances on two threads for stereo, src/Frame.cc:114-117), one handle may not.
+ * instances on two threads for stereo, src/Frame.cc:114-117), one handle may not. Every entry point
+ * makes its handle's device current for the duration of the call and restores the calling thread's
+ * device before it returns.
  */
 #ifndef ORBHIP_H
 #define ORBHIP_H
@@ -93,10 +95,33 @@ int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int 
                                 orbhip_keypoint* d_kp, uint8_t* d_desc, int* d_counts, int cap,
                                 void* stream);
 
-/* Host-buffer variant of the batch call (copies in, extracts, copies out, waits). */
+/* Host-buffer variant of the batch call: what Frame::ExtractORB (src/Frame.cc:272-278) does per image, for
+ * `nframes` images in host memory; waits for the results. Batches of 8 frames and more run as a pipeline of
+ * chunks (about 64 MB of images each, ORBHIP_HOST_CHUNK=n frames overrides) over three internal streams and
+ * workspaces: while one chunk is packed into page-locked memory by a few host threads (ORBHIP_PACK_THREADS,
+ * default half of the CPUs the process may use, at most 8), the previous one travels to the device, the one
+ * before is extracted and the results of the one before that travel back. Images that already lie in
+ * page-locked memory (hipHostMalloc / hipHostRegister) are copied from where they are, without the packing
+ * step. ORBHIP_HOST_PIPELINE=0 (read by orbhip_create) restores one copy up, all passes, one copy down.
+ * After the call orbhip_pyramid_copy sees the frames of the last chunk only. */
 int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int nframes, int width, int height,
                          size_t row_stride, size_t frame_stride, orbhip_keypoint* kp, uint8_t* desc,
                          int* counts, int cap);
+
+/* Several GPUs (or several handles on one GPU) from one process. The reference runs its two extractor instances
+ * on two threads inside one process (src/Frame.cc:114-117); this is the same arrangement for a batch: the frames
+ * are cut into `nhandles` contiguous ranges (orbhip_shard_range), handle i extracts range i on its own device
+ * with its own host thread, and every thread writes its frames' results where they belong in the caller's
+ * arrays: no collective, no exchange between devices, a host-side gather only. Arguments and results are those
+ * of orbhip_extract_batch (gray images); the handles must be distinct and configured alike. Returns the first
+ * failing handle's status (its message through orbhip_last_error(handles[0])). Like every entry point of this
+ * library the call leaves the calling thread's current HIP device as it found it. */
+int orbhip_extract_batch_multi(orbhip_extractor* const* handles, int nhandles, const uint8_t* imgs, int nframes,
+                               int width, int height, size_t row_stride, size_t frame_stride,
+                               orbhip_keypoint* kp, uint8_t* desc, int* counts, int cap);
+/* The range [*lo, *hi) of `nframes` frames that shard `index` of `nshards` owns: contiguous, sizes differing by at
+ * most one group of `group` frames (group = 2 keeps the two images of an interleaved stereo pair together). */
+int orbhip_shard_range(int nframes, int nshards, int index, int group, int* lo, int* hi);
 
 /* The same two calls for interleaved 8-bit colour images: the cvtColor to gray that precedes the
  * extraction in the reference (Tracking::GrabImageStereo / GrabImageRGBD / GrabImageMonocular,
@@ -229,6 +254,20 @@ int orbhip_extract_stereo_batch_device(orbhip_extractor* left, orbhip_extractor*
                                        orbhip_keypoint* d_kp_l, uint8_t* d_desc_l, int* d_cnt_l,
                                        orbhip_keypoint* d_kp_r, uint8_t* d_desc_r, int* d_cnt_r, int cap,
                                        float mb, float mbf, float* d_uright, float* d_depth, int* d_nmatch, void* stream);
+/* The same for pairs in host memory, results into host arrays ([npairs][cap] records per side, [npairs][cap]
+ * floats of mvuRight / mvDepth, nmatch[npairs] or NULL); waits for the results. */
+int orbhip_extract_stereo_batch(orbhip_extractor* left, orbhip_extractor* right, const uint8_t* imgs_l, const uint8_t* imgs_r,
+                                int npairs, int width, int height, size_t row_stride, size_t frame_stride,
+                                orbhip_keypoint* kp_l, uint8_t* desc_l, int* cnt_l, orbhip_keypoint* kp_r, uint8_t* desc_r, int* cnt_r,
+                                int cap, float mb, float mbf, float* uright, float* depth, int* nmatch);
+/* ... sharded over `nhandles` pairs of instances (left[i], right[i] on one device each) like
+ * orbhip_extract_batch_multi: contiguous ranges of pairs, both images of a pair on the same device (the matcher
+ * reads both pyramids there), one host thread per pair of handles, no exchange between devices. */
+int orbhip_extract_stereo_batch_multi(orbhip_extractor* const* left, orbhip_extractor* const* right, int nhandles,
+                                      const uint8_t* imgs_l, const uint8_t* imgs_r, int npairs, int width, int height,
+                                      size_t row_stride, size_t frame_stride,
+                                      orbhip_keypoint* kp_l, uint8_t* desc_l, int* cnt_l, orbhip_keypoint* kp_r, uint8_t* desc_r, int* cnt_r,
+                                      int cap, float mb, float mbf, float* uright, float* depth, int* nmatch);
 /* The same for one pair with host arrays (the last orbhip_extract of each instance): kp/desc as
  * returned by orbhip_extract, uright / depth receive n_l floats. Waits for the result. */
 int orbhip_stereo_match(orbhip_extractor* left, orbhip_extractor* right,

@@ -912,6 +912,12 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const PlanDev* __restrict__ p
         L = Lnew;
         cur = nxt;
     }
+    if (!done || best == nullptr) {
+        // the round limit ended the loop (a node is split down to single pixels in far fewer rounds than that): no
+        // keypoints for this level and an error for the call, rather than a read through a pointer that was never set
+        if (tid == 0) { atomicOr(status, 4); lvl_cnt[f * plan->nlevels + level] = 0; }
+        return;
+    }
     // ---- output in list order
     LevelKp* out = lvl_kp + (size_t)f * plan->kp_per_frame + g.kp_off;
     for (int i = tid; i < L; i += QT_T) {

@@ -5,6 +5,7 @@
 // kernel launches over a pass of up to max_batch frames. There is no CPU fallback: every entry
 // point fails with an error code when HIP is unavailable.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <cmath>
@@ -12,6 +13,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/orbhip.h"
@@ -67,6 +69,7 @@ const int kLanes = 4;
 const int kQtSmallQuota = 300;
 const int kQtLatencyGroups = 256;   // (frames x levels) up to this: a pass that cannot fill the chip
 const int kMinLaneFrames = 16;     // batches below twice this run as one pass on the caller's stream
+const int kPipelineMinFrames = 8;  // host batches from this size on are cut into chunks that overlap copy, extraction and copy back
 
 } // namespace
 
@@ -152,9 +155,16 @@ struct orbhip_extractor {
     // is seen and replayed from then on (ORBHIP_GRAPH=0: never). config_gen counts everything that
     // invalidates the captured pointers: a new plan, new staging buffers, new rectification maps.
     int use_graph = 1;
+    int host_pipeline = 1;         // ORBHIP_HOST_PIPELINE=0: the host batch call runs as one copy up, all passes, one copy down
+    int host_chunk = 0;            // ORBHIP_HOST_CHUNK=n: frames per chunk of the pipelined host batch call (0: about 64 MB of images)
     hipGraphExec_t graph_exec = nullptr;
     struct GraphKey { int w, h, channels, rgb, cap; unsigned long long gen; } graph_key = {0, 0, 0, 0, 0, 0}, graph_seen = {0, 0, 0, 0, 0, 0};
     unsigned long long config_gen = 1;
+    // what run_pass noted about level 0 in ws[0] while the graph was captured (the captured kernels carry that view by
+    // value): written back on every replay, since other calls on the handle leave their own view there in between
+    Level0View graph_v0 = {nullptr, 0, 0, 0};
+    const uint8_t* graph_l0_src = nullptr;
+    size_t graph_l0_row_stride = 0, graph_l0_frame_stride = 0;
     // staging for the host entry points
     uint8_t* d_in = nullptr; size_t d_in_bytes = 0;
     uint8_t* h_in = nullptr; size_t h_in_bytes = 0;      // pinned: rows are packed here, then one copy up
@@ -167,6 +177,7 @@ struct orbhip_extractor {
     int* d_st_bins = nullptr; size_t d_st_bins_n = 0;    // [frames][nbins + 1] record range of every row bin
     uint8_t* d_st_tmp = nullptr; size_t d_st_tmp_bytes = 0;   // staging of the host-array entry point
     uint8_t* d_match_spill = nullptr; size_t d_match_spill_bytes = 0;   // matcher state of frames too large for LDS
+    uint8_t* d_st_host = nullptr; uint8_t* h_st_host = nullptr; size_t st_host_bytes = 0;   // mvuRight / mvDepth / match counts of the host stereo batch call
     // timing
     bool timing = false;
     std::vector<TimedSpan> spans;
@@ -185,6 +196,28 @@ namespace {
             return ORBHIP_ERR_HIP;                                                           \
         }                                                                                    \
     } while (0)
+
+// Every entry point works on its handle's device and leaves the calling thread's current device as it
+// found it: a host that drives several GPUs from one process (one handle per device, as the reference runs
+// its two extractor instances side by side, src/Frame.cc:114-117) never finds it changed under its feet.
+struct DeviceScope {
+    int prev = -1;
+    hipError_t st;
+    explicit DeviceScope(int dev) {
+        int cur = -1;
+        st = hipGetDevice(&cur);
+        if (st == hipSuccess && cur != dev) {
+            st = hipSetDevice(dev);
+            if (st == hipSuccess) prev = cur;
+        }
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+#define DEVICE_SCOPE(e)                         \
+    DeviceScope _device_scope((e)->device);     \
+    HIP_TRY(e, _device_scope.st)
 
 template <typename T>
 void dfree(T*& p) {
@@ -424,7 +457,7 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
             }
         }
     }
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     HIP_TRY(e, hipMalloc(&e->d_plan, sizeof(PlanDev)));
     HIP_TRY(e, hipMalloc(&e->d_tabs, tabs.size() * sizeof(RsTab)));
     for (int k = 0; k < lanes; k++) {
@@ -644,7 +677,7 @@ int check_status(orbhip_extractor* e) {
     HIP_TRY(e, hipMemcpy(&st, e->d_status, sizeof(int), hipMemcpyDeviceToHost));
     if (st) {
         (void)hipMemset(e->d_status, 0, sizeof(int));
-        e->err = (st & 1) ? "internal candidate capacity exceeded" : "output capacity (cap) too small";
+        e->err = (st & 1) ? "internal candidate capacity exceeded" : (st & 4) ? "internal: quadtree round limit reached" : "output capacity (cap) too small";
         return ORBHIP_ERR_CAPACITY;
     }
     return ORBHIP_OK;
@@ -711,7 +744,8 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
         ++v0;
     }
     std::memcpy(e->umax, um, sizeof(e->umax));
-    if (hipSetDevice(e->device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+    DeviceScope device_scope(e->device);
+    if (device_scope.st != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(&e->d_status, sizeof(int)) != hipSuccess || hipMemset(e->d_status, 0, sizeof(int)) != hipSuccess) {
         delete e;
         return ORBHIP_ERR_HIP;
@@ -736,6 +770,8 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
     if (const char* v = std::getenv("ORBHIP_INPLACE_LEVEL0")) e->inplace_l0 = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_FAST_PACK")) e->fast_pack = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_GRAPH")) e->use_graph = std::atoi(v) != 0;
+    if (const char* v = std::getenv("ORBHIP_HOST_PIPELINE")) e->host_pipeline = std::atoi(v) != 0;
+    if (const char* v = std::getenv("ORBHIP_HOST_CHUNK")) e->host_chunk = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("ORBHIP_QT_LDS_LIMIT")) e->qt_lds_limit = std::min<size_t>(160 * 1024 - 256, (size_t)std::max(std::atoi(v), 1024));
     *out = e;
     return ORBHIP_OK;
@@ -743,7 +779,7 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
 
 int orbhip_destroy(orbhip_extractor* e) {
     if (!e) return ORBHIP_ERR_ARG;
-    (void)hipSetDevice(e->device);
+    DeviceScope device_scope(e->device);
     (void)hipDeviceSynchronize();
     collect_timing(e);
     for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
@@ -751,7 +787,8 @@ int orbhip_destroy(orbhip_extractor* e) {
     free_plan(e);
     dfree(e->d_status); dfree(e->d_in); dfree(e->d_out_kp); dfree(e->d_out_desc); dfree(e->d_out_cnt);
     dfree(e->d_st_sad); dfree(e->d_st_rinfo); dfree(e->d_st_bins); dfree(e->d_st_tmp); dfree(e->d_match_spill);
-    dfree(e->d_map_x); dfree(e->d_map_y);
+    dfree(e->d_map_x); dfree(e->d_map_y); dfree(e->d_st_host);
+    if (e->h_st_host) (void)hipHostFree(e->h_st_host);
     if (e->h_in) (void)hipHostFree(e->h_in);
     if (e->h_out) (void)hipHostFree(e->h_out);
     if (e->h_pyr) (void)hipHostFree(e->h_pyr);
@@ -794,7 +831,7 @@ static int extract_device_impl(orbhip_extractor* e, const uint8_t* d_imgs, int n
         e->err = "rectification maps are set: the input must be a gray image of the maps' size";
         return ORBHIP_ERR_ARG;
     }
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     // A handle has one set of workspaces: a call on another stream than the previous one waits for
     // that call's work before it touches them.
@@ -853,10 +890,220 @@ int orbhip_extract_batch_device_color(orbhip_extractor* e, const uint8_t* d_imgs
 
 int orbhip_synchronize(orbhip_extractor* e) {
     if (!e) return ORBHIP_ERR_ARG;
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     HIP_TRY(e, hipDeviceSynchronize());
     collect_timing(e);
     return check_status(e);
+}
+
+// Worker threads for packing a chunk of caller images into pinned memory: half of the CPUs this process may
+// run on, at most 8 (ORBHIP_PACK_THREADS overrides; a GPU box reports the whole machine in
+// hardware_concurrency, the affinity mask is what the process really has).
+static int pack_threads() {
+    static const int n = [] {
+        if (const char* v = std::getenv("ORBHIP_PACK_THREADS")) return std::min(32, std::max(1, std::atoi(v)));
+        int c = 1;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) c = CPU_COUNT(&set);
+        return std::max(1, std::min(c / 2, 8));
+    }();
+    return n;
+}
+
+// Rows [r0, r1) of the `n` frames starting at `src` (rows counted through all frames) into the staging layout
+// (rows of dev_row bytes, frames of height rows). The caller owns width_bytes of every source row, not the
+// padding behind it.
+static void pack_rows(const uint8_t* src, size_t row_stride, size_t frame_stride, uint8_t* dst, size_t dev_row, int height,
+                      size_t width_bytes, size_t r0, size_t r1) {
+    while (r0 < r1) {
+        const size_t f = r0 / (size_t)height, y0 = r0 - f * (size_t)height;
+        const size_t y1 = std::min((size_t)height, y0 + (r1 - r0));
+        const uint8_t* s = src + f * frame_stride + y0 * row_stride;
+        uint8_t* d = dst + (f * (size_t)height + y0) * dev_row;
+        if (row_stride == dev_row) std::memcpy(d, s, (y1 - y0 - 1) * row_stride + width_bytes);
+        else for (size_t y = y0; y < y1; y++, s += row_stride, d += dev_row) std::memcpy(d, s, width_bytes);
+        r0 += y1 - y0;
+    }
+}
+
+static void pack_frames(const uint8_t* src, size_t row_stride, size_t frame_stride, uint8_t* dst, size_t dev_row, int height,
+                        size_t width_bytes, int n) {
+    const size_t rows = (size_t)n * (size_t)height;
+    const size_t bytes = rows * width_bytes;
+    const int nt = (int)std::min<size_t>((size_t)pack_threads(), std::max<size_t>(1, bytes >> 22));   // a thread per 4 MB at least
+    if (nt <= 1) { pack_rows(src, row_stride, frame_stride, dst, dev_row, height, width_bytes, 0, rows); return; }
+    std::vector<std::thread> th;
+    th.reserve((size_t)nt - 1);
+    for (int t = 1; t < nt; t++)
+        th.emplace_back(pack_rows, src, row_stride, frame_stride, dst, dev_row, height, width_bytes, rows * t / nt, rows * (t + 1) / nt);
+    pack_rows(src, row_stride, frame_stride, dst, dev_row, height, width_bytes, 0, rows / nt);
+    for (std::thread& t : th) t.join();
+}
+
+// true when `p` is page-locked host memory the GPU can copy from directly (hipHostMalloc / hipHostRegister)
+static bool host_pointer_is_pinned(const void* p) {
+    hipPointerAttribute_t a;
+    std::memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+// Staging buffers of the host entry points: in_bytes of device and pinned input, outputs of out_frames frames
+// (device) and their pinned copy: [status word, 16 bytes][counts][keypoints][descriptors].
+struct HostStage { uint8_t *h_status, *h_cnt, *h_kp, *h_desc; size_t kp_bytes, desc_bytes; };
+static int host_staging(orbhip_extractor* e, size_t in_bytes, bool need_pinned_in, int out_frames, int cap, HostStage* hs) {
+    if (in_bytes > e->d_in_bytes) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        // a pass that read its level 0 in place from the old staging buffer loses it
+        for (Workspace& w : e->ws)
+            if (w.l0_src && w.l0_src >= e->d_in && w.l0_src < e->d_in + e->d_in_bytes) {
+                w.v0 = Level0View{nullptr, 0, 0, 0}; w.l0_src = nullptr; w.l0_in_plane = true;
+                e->last_pass_frames = 0;
+            }
+        dfree(e->d_in);
+        e->d_in_bytes = 0;
+        HIP_TRY(e, hipMalloc(&e->d_in, in_bytes));
+        e->d_in_bytes = in_bytes;
+        e->config_gen++;
+    }
+    if (need_pinned_in && in_bytes > e->h_in_bytes) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        e->config_gen++;
+        if (e->h_in) (void)hipHostFree(e->h_in);
+        e->h_in = nullptr; e->h_in_bytes = 0;
+        HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_in), in_bytes, hipHostMallocDefault));
+        e->h_in_bytes = in_bytes;
+    }
+    if ((size_t)out_frames > e->d_out_frames || cap != e->d_out_cap) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        e->config_gen++;
+        dfree(e->d_out_kp); dfree(e->d_out_desc); dfree(e->d_out_cnt);
+        e->d_out_frames = 0;
+        HIP_TRY(e, hipMalloc(&e->d_out_kp, (size_t)out_frames * cap * sizeof(orbhip_keypoint)));
+        HIP_TRY(e, hipMalloc(&e->d_out_desc, (size_t)out_frames * cap * 32));
+        HIP_TRY(e, hipMalloc(&e->d_out_cnt, (size_t)out_frames * sizeof(int)));
+        e->d_out_frames = out_frames; e->d_out_cap = cap;
+    }
+    hs->kp_bytes = (size_t)out_frames * cap * sizeof(orbhip_keypoint);
+    hs->desc_bytes = (size_t)out_frames * cap * 32;
+    const size_t cnt_bytes = ((size_t)out_frames * sizeof(int) + 15) & ~(size_t)15;
+    const size_t total = 16 + cnt_bytes + hs->kp_bytes + hs->desc_bytes;
+    if (total > e->h_out_bytes) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        e->config_gen++;
+        if (e->h_out) (void)hipHostFree(e->h_out);
+        e->h_out = nullptr; e->h_out_bytes = 0;
+        HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_out), total, hipHostMallocDefault));
+        e->h_out_bytes = total;
+    }
+    hs->h_status = e->h_out;
+    hs->h_cnt = e->h_out + 16;
+    hs->h_kp = hs->h_cnt + cnt_bytes;
+    hs->h_desc = hs->h_kp + hs->kp_bytes;
+    return ORBHIP_OK;
+}
+
+// The status word arrives with the results (one more small copy on the stream, no blocking copy of its own).
+static int host_status(orbhip_extractor* e, const HostStage& hs, hipStream_t s) {
+    const int st = *reinterpret_cast<const volatile int*>(hs.h_status);
+    if (!st) return ORBHIP_OK;
+    (void)hipMemsetAsync(e->d_status, 0, sizeof(int), s);
+    e->err = (st & 1) ? "internal candidate capacity exceeded" : (st & 4) ? "internal: quadtree round limit reached" : "output capacity (cap) too small";
+    return ORBHIP_ERR_CAPACITY;
+}
+
+static void unpack_frames(const HostStage& hs, int f0, int n, int cap, orbhip_keypoint* kp, uint8_t* desc, int* counts) {
+    std::memcpy(counts + f0, hs.h_cnt + (size_t)f0 * sizeof(int), (size_t)n * sizeof(int));
+    for (int f = f0; f < f0 + n; f++) {
+        const int m = std::min(counts[f], cap);
+        if (m <= 0) continue;
+        std::memcpy(kp + (size_t)f * cap, hs.h_kp + (size_t)f * cap * sizeof(orbhip_keypoint), (size_t)m * sizeof(orbhip_keypoint));
+        std::memcpy(desc + (size_t)f * cap * 32, hs.h_desc + (size_t)f * cap * 32, (size_t)m * 32);
+    }
+}
+
+// A batch of host images as a pipeline of chunks over up to three workspaces and streams: while chunk k's images are
+// packed into pinned memory by a few host threads (or read straight from the caller's buffer when that is page-locked),
+// chunk k-1 is on its way up, chunk k-2 is being extracted and the results of chunk k-3 are copied down and handed to
+// the caller's arrays. What Frame::ExtractORB does per image (src/Frame.cc:272-278) for many images in host memory;
+// the transfer over PCIe is what bounds it.
+static int extract_host_pipelined(orbhip_extractor* e, const uint8_t* imgs, int nframes, int width, int height,
+                                  size_t row_stride, size_t frame_stride, int channels, int rgb, orbhip_keypoint* kp,
+                                  uint8_t* desc, int* counts, int cap) {
+    const size_t width_bytes = (size_t)width * channels;
+    const size_t dev_row = (width_bytes + 15) & ~(size_t)15, dev_frame = dev_row * height;
+    const int budget = pass_budget(e, width, height);
+    int chunk = e->host_chunk > 0 ? e->host_chunk : (int)std::max<size_t>(4, ((size_t)64 << 20) / dev_frame);
+    chunk = std::min(chunk, (nframes + 3) / 4);                // four chunks at least, so that the stages overlap
+    chunk = std::max(1, std::min(chunk, budget));
+    const int nchunks = (nframes + chunk - 1) / chunk;
+    const int nl = std::min(3, nchunks);
+    const bool pinned = host_pointer_is_pinned(imgs);
+    HostStage hs;
+    int rc = host_staging(e, (size_t)nl * chunk * dev_frame, !pinned, nframes, cap, &hs);
+    if (rc) return rc;
+    // earlier work of this handle (on whatever stream) is over before the workspaces are touched
+    if (e->last_stream) HIP_TRY(e, hipEventSynchronize(e->ev_busy));
+    if (e->plan_w != width || e->plan_h != height || e->plan_frames < chunk || e->plan_lanes < nl) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        const bool same = e->plan_w == width && e->plan_h == height;
+        rc = ensure_plan(e, width, height, std::max(chunk, same ? e->plan_frames : 0), std::max(nl, same ? e->plan_lanes : 0));
+        if (rc) return rc;
+    }
+    if (e->d_map_x && (channels != 1 || width != e->map_w || height != e->map_h || width < 2 || height < 2)) {
+        e->err = "rectification maps are set: the input must be a gray image of the maps' size";
+        return ORBHIP_ERR_ARG;
+    }
+    auto fail = [&](int code) { (void)hipDeviceSynchronize(); return code; };   // nothing of this call stays in flight
+    hipStream_t last = e->ws[0].stream;
+    for (int k = 0; k < nchunks + nl; k++) {
+        const int lane = k % nl;
+        Workspace& W = e->ws[lane];
+        if (k >= nl) {                                         // chunk k - nl ran on this lane: its results are down
+            if (hipEventSynchronize(W.done) != hipSuccess) { e->err = "a chunk of the batch failed on the device"; return fail(ORBHIP_ERR_HIP); }
+            const int j0 = (k - nl) * chunk;
+            unpack_frames(hs, j0, std::min(chunk, nframes - j0), cap, kp, desc, counts);
+        }
+        if (k >= nchunks) continue;
+        const int f0 = k * chunk, n = std::min(chunk, nframes - f0);
+        hipStream_t s = W.stream;
+        uint8_t* d_in = e->d_in + (size_t)lane * chunk * dev_frame;
+        const uint8_t* src = imgs + (size_t)f0 * frame_stride;
+        hipError_t st = hipSuccess;
+        if (pinned) {
+            if (row_stride == dev_row && frame_stride == dev_frame)
+                st = hipMemcpyAsync(d_in, src, (size_t)n * dev_frame - (dev_row - width_bytes), hipMemcpyHostToDevice, s);
+            else if (frame_stride == row_stride * (size_t)height)
+                st = hipMemcpy2DAsync(d_in, dev_row, src, row_stride, width_bytes, (size_t)height * n, hipMemcpyHostToDevice, s);
+            else
+                for (int f = 0; f < n && st == hipSuccess; f++)
+                    st = hipMemcpy2DAsync(d_in + (size_t)f * dev_frame, dev_row, src + (size_t)f * frame_stride, row_stride, width_bytes,
+                                          (size_t)height, hipMemcpyHostToDevice, s);
+        } else {
+            uint8_t* h_in = e->h_in + (size_t)lane * chunk * dev_frame;
+            pack_frames(src, row_stride, frame_stride, h_in, dev_row, height, width_bytes, n);
+            st = hipMemcpyAsync(d_in, h_in, (size_t)n * dev_frame, hipMemcpyHostToDevice, s);
+        }
+        if (st != hipSuccess) { e->err = std::string("copy of a chunk to the device: ") + hipGetErrorString(st); return fail(ORBHIP_ERR_HIP); }
+        rc = run_pass(e, W, s, d_in, n, dev_row, dev_frame, dev_row, channels, rgb, e->d_out_kp, e->d_out_desc, e->d_out_cnt, cap, f0);
+        if (rc) return fail(rc);
+        const size_t o = (size_t)f0 * cap;
+        st = hipMemcpyAsync(hs.h_cnt + (size_t)f0 * sizeof(int), e->d_out_cnt + f0, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s);
+        if (st == hipSuccess) st = hipMemcpyAsync(hs.h_kp + o * sizeof(orbhip_keypoint), e->d_out_kp + o * 7, (size_t)n * cap * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, s);
+        if (st == hipSuccess) st = hipMemcpyAsync(hs.h_desc + o * 32, e->d_out_desc + o * 32, (size_t)n * cap * 32, hipMemcpyDeviceToHost, s);
+        if (st == hipSuccess && k == nchunks - 1) st = hipMemcpyAsync(hs.h_status, e->d_status, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (st == hipSuccess) st = hipEventRecord(W.done, s);
+        if (st != hipSuccess) { e->err = std::string("copy of a chunk's results: ") + hipGetErrorString(st); return fail(ORBHIP_ERR_HIP); }
+        last = s;
+    }
+    // (the status word was read behind the last chunk's results, but chunks overlap: drain the other lanes before trusting it)
+    HIP_TRY(e, hipDeviceSynchronize());
+    HIP_TRY(e, hipMemcpyAsync(hs.h_status, e->d_status, sizeof(int), hipMemcpyDeviceToHost, last));
+    HIP_TRY(e, hipStreamSynchronize(last));
+    e->last_stream = last;
+    HIP_TRY(e, hipEventRecord(e->ev_busy, last));
+    collect_timing(e);
+    return host_status(e, hs, last);
 }
 
 static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nframes, int width, int height,
@@ -866,57 +1113,18 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
         return ORBHIP_ERR_ARG;
     if (!imgs || width <= 0 || height <= 0 || nframes == 0) return ORBHIP_ERR_EMPTY;
     if (row_stride < (size_t)width * channels) return ORBHIP_ERR_ARG;
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
+    if (nframes >= kPipelineMinFrames && e->host_pipeline)
+        return extract_host_pipelined(e, imgs, nframes, width, height, row_stride, frame_stride, channels, rgb, kp, desc, counts, cap);
     const size_t dev_row = ((size_t)width * channels + 15) & ~(size_t)15, dev_frame = dev_row * height;
     const size_t need = dev_frame * nframes;
-    if (need > e->d_in_bytes) {
-        HIP_TRY(e, hipDeviceSynchronize());
-        // a pass that read its level 0 in place from the old staging buffer loses it
-        for (Workspace& w : e->ws)
-            if (w.l0_src && w.l0_src >= e->d_in && w.l0_src < e->d_in + e->d_in_bytes) {
-                w.v0 = Level0View{nullptr, 0, 0, 0}; w.l0_src = nullptr; w.l0_in_plane = true;
-                e->last_pass_frames = 0;
-            }
-        dfree(e->d_in);
-        HIP_TRY(e, hipMalloc(&e->d_in, need));
-        e->d_in_bytes = need;
-        e->config_gen++;
-    }
-    if (need > e->h_in_bytes) {
-        e->config_gen++;
-        if (e->h_in) (void)hipHostFree(e->h_in);
-        e->h_in = nullptr; e->h_in_bytes = 0;
-        HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_in), need, hipHostMallocDefault));
-        e->h_in_bytes = need;
-    }
-    if ((size_t)nframes > e->d_out_frames || cap != e->d_out_cap) {
-        HIP_TRY(e, hipDeviceSynchronize());
-        e->config_gen++;
-        dfree(e->d_out_kp); dfree(e->d_out_desc); dfree(e->d_out_cnt);
-        HIP_TRY(e, hipMalloc(&e->d_out_kp, (size_t)nframes * cap * sizeof(orbhip_keypoint)));
-        HIP_TRY(e, hipMalloc(&e->d_out_desc, (size_t)nframes * cap * 32));
-        HIP_TRY(e, hipMalloc(&e->d_out_cnt, (size_t)nframes * sizeof(int)));
-        e->d_out_frames = nframes; e->d_out_cap = cap;
-    }
-    const size_t kp_bytes = (size_t)nframes * cap * sizeof(orbhip_keypoint), desc_bytes = (size_t)nframes * cap * 32;
-    const size_t cnt_bytes = ((size_t)nframes * sizeof(int) + 15) & ~(size_t)15;
-    if (kp_bytes + desc_bytes + cnt_bytes > e->h_out_bytes) {
-        e->config_gen++;
-        if (e->h_out) (void)hipHostFree(e->h_out);
-        e->h_out = nullptr; e->h_out_bytes = 0;
-        HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_out), kp_bytes + desc_bytes + cnt_bytes, hipHostMallocDefault));
-        e->h_out_bytes = kp_bytes + desc_bytes + cnt_bytes;
-    }
+    HostStage hs;
+    int rc = host_staging(e, need, true, nframes, cap, &hs);
+    if (rc) return rc;
+    const size_t kp_bytes = hs.kp_bytes, desc_bytes = hs.desc_bytes;
     // pack the rows into the pinned buffer (a 2-D copy from pageable memory would go row by row)
-    for (int f = 0; f < nframes; f++) {
-        const uint8_t* src = imgs + (size_t)f * frame_stride;
-        uint8_t* dst = e->h_in + (size_t)f * dev_frame;
-        // (the caller owns width * channels bytes of every row, not the padding behind the last one)
-        if (row_stride == dev_row) std::memcpy(dst, src, (size_t)(height - 1) * row_stride + (size_t)width * channels);
-        else for (int y = 0; y < height; y++) std::memcpy(dst + (size_t)y * dev_row, src + (size_t)y * row_stride, (size_t)width * channels);
-    }
-    uint8_t* h_cnt = e->h_out, *h_kp = e->h_out + cnt_bytes, *h_desc = h_kp + kp_bytes;
-    int rc = ORBHIP_OK;
+    pack_frames(imgs, row_stride, frame_stride, e->h_in, dev_row, height, (size_t)width * channels, nframes);
+    uint8_t* h_cnt = hs.h_cnt, *h_kp = hs.h_kp, *h_desc = hs.h_desc;
     // One frame through a plan that exists: replay the captured graph, or capture it when this configuration
     // comes a second time (the first call of a configuration builds plan and buffers and runs the plain way).
     const orbhip_extractor::GraphKey key = {width, height, channels, rgb, cap, e->config_gen};
@@ -939,12 +1147,16 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
             st = hipMemcpyAsync(h_cnt, e->d_out_cnt, sizeof(int), hipMemcpyDeviceToHost, e->stream);
             if (st == hipSuccess) st = hipMemcpyAsync(h_kp, e->d_out_kp, kp_bytes, hipMemcpyDeviceToHost, e->stream);
             if (st == hipSuccess) st = hipMemcpyAsync(h_desc, e->d_out_desc, desc_bytes, hipMemcpyDeviceToHost, e->stream);
+            if (st == hipSuccess) st = hipMemcpyAsync(hs.h_status, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream);
         }
         const hipError_t end = hipStreamEndCapture(e->stream, &graph);   // always: the stream must leave capture mode
         if (prc == ORBHIP_OK && st == hipSuccess && end == hipSuccess && graph &&
-            hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess)
+            hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
             e->graph_key = key;
-        else {
+            const Workspace& W = e->ws[0];
+            e->graph_v0 = W.v0; e->graph_l0_src = W.l0_src;
+            e->graph_l0_row_stride = W.l0_row_stride; e->graph_l0_frame_stride = W.l0_frame_stride;
+        } else {
             e->graph_exec = nullptr;                               // capture is not available here: plain launches from now on
             e->use_graph = 0;
         }
@@ -956,8 +1168,11 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
         e->last_stream = e->stream;
         HIP_TRY(e, hipGraphLaunch(e->graph_exec, e->stream));
         HIP_TRY(e, hipEventRecord(e->ev_busy, e->stream));
-        // what run_pass notes on the host for a pass
+        // what run_pass notes on the host for a pass (the level-0 view is the captured one, whatever another
+        // call on this handle left in the workspace since)
         Workspace& W = e->ws[0];
+        W.v0 = e->graph_v0; W.l0_src = e->graph_l0_src;
+        W.l0_row_stride = e->graph_l0_row_stride; W.l0_frame_stride = e->graph_l0_frame_stride;
         W.l0_in_plane = W.v0.org == nullptr;
         e->last_pass_frames = 1; e->last_ws = 0; e->pass_gen++;
         replayed = true;
@@ -972,18 +1187,13 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
         HIP_TRY(e, hipMemcpyAsync(h_cnt, e->d_out_cnt, (size_t)nframes * sizeof(int), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipMemcpyAsync(h_kp, e->d_out_kp, kp_bytes, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipMemcpyAsync(h_desc, e->d_out_desc, desc_bytes, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(hs.h_status, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     }
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     collect_timing(e);
-    rc = check_status(e);
+    rc = host_status(e, hs, e->stream);
     if (rc) return rc;
-    std::memcpy(counts, h_cnt, (size_t)nframes * sizeof(int));
-    for (int f = 0; f < nframes; f++) {
-        const int n = std::min(counts[f], cap);
-        if (n <= 0) continue;
-        std::memcpy(kp + (size_t)f * cap, h_kp + (size_t)f * cap * sizeof(orbhip_keypoint), (size_t)n * sizeof(orbhip_keypoint));
-        std::memcpy(desc + (size_t)f * cap * 32, h_desc + (size_t)f * cap * 32, (size_t)n * 32);
-    }
+    unpack_frames(hs, 0, nframes, cap, kp, desc, counts);
     return ORBHIP_OK;
 }
 
@@ -991,6 +1201,45 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int nframes, 
                          size_t row_stride, size_t frame_stride, orbhip_keypoint* kp, uint8_t* desc,
                          int* counts, int cap) {
     return extract_host_impl(e, imgs, nframes, width, height, row_stride, frame_stride, 1, 0, kp, desc, counts, cap);
+}
+
+int orbhip_shard_range(int nframes, int nshards, int index, int group, int* lo, int* hi) {
+    if (!lo || !hi || nframes < 0 || nshards < 1 || index < 0 || index >= nshards || group < 1 || nframes % group) return ORBHIP_ERR_ARG;
+    const int ngroups = nframes / group, base = ngroups / nshards, rem = ngroups % nshards;
+    const int first = index * base + std::min(index, rem);
+    *lo = first * group;
+    *hi = (first + base + (index < rem ? 1 : 0)) * group;
+    return ORBHIP_OK;
+}
+
+int orbhip_extract_batch_multi(orbhip_extractor* const* handles, int nhandles, const uint8_t* imgs, int nframes, int width, int height,
+                               size_t row_stride, size_t frame_stride, orbhip_keypoint* kp, uint8_t* desc, int* counts, int cap) {
+    if (!handles || nhandles < 1 || !kp || !desc || !counts || cap < 1 || nframes < 0) return ORBHIP_ERR_ARG;
+    for (int i = 0; i < nhandles; i++) {
+        if (!handles[i]) return ORBHIP_ERR_ARG;
+        for (int j = 0; j < i; j++) if (handles[j] == handles[i]) return ORBHIP_ERR_ARG;   // a handle serves one thread at a time
+    }
+    if (!imgs || width <= 0 || height <= 0 || nframes == 0) return ORBHIP_ERR_EMPTY;
+    // one host thread per handle, each with its own contiguous range of frames and its own slices of the outputs:
+    // no exchange between the handles, the "gather" is that every thread writes where its frames belong
+    std::vector<int> rcs((size_t)nhandles, ORBHIP_OK);
+    auto work = [&](int i) {
+        int lo = 0, hi = 0;
+        orbhip_shard_range(nframes, nhandles, i, 1, &lo, &hi);
+        if (hi <= lo) return;
+        rcs[(size_t)i] = extract_host_impl(handles[i], imgs + (size_t)lo * frame_stride, hi - lo, width, height, row_stride, frame_stride, 1, 0,
+                                           kp + (size_t)lo * cap, desc + (size_t)lo * cap * 32, counts + lo, cap);
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < nhandles; i++) th.emplace_back(work, i);
+    work(0);
+    for (std::thread& t : th) t.join();
+    for (int i = 0; i < nhandles; i++)
+        if (rcs[(size_t)i]) {
+            if (i) handles[0]->err = "handle " + std::to_string(i) + ": " + handles[i]->err;
+            return rcs[(size_t)i];
+        }
+    return ORBHIP_OK;
 }
 
 int orbhip_extract(orbhip_extractor* e, const uint8_t* img, int width, int height, size_t stride,
@@ -1074,7 +1323,7 @@ int orbhip_pyramid_copy(orbhip_extractor* e, int frame, int level, uint8_t* dst,
     const LevelGeom& g = e->plan.lv[level];
     const int b = with_border ? ORB_EDGE : 0;
     if (dst_stride < (size_t)(g.w + 2 * b)) return ORBHIP_ERR_ARG;
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     // The first request for a frame after a pass brings all levels of that frame into pinned host
     // memory (one asynchronous copy per level, one wait: callers such as the C++ class ask for every
     // level in turn); the rows are then cut out on the host (a 2-D copy into pageable memory would
@@ -1130,7 +1379,7 @@ int orbhip_debug_candidates(orbhip_extractor* e, int frame, int level, orbhip_ca
     const PlanDev& P = e->plan;
     const LevelGeom& g = P.lv[level];
     if (g.ncols < 1) return 0;
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     HIP_TRY(e, hipDeviceSynchronize());
     int n = 0;
     const Workspace& W = e->ws[e->last_ws];
@@ -1164,7 +1413,7 @@ int orbhip_debug_level_keypoints(orbhip_extractor* e, int frame, int level, uint
     if (!e->plan_w || frame < 0 || frame >= e->last_pass_frames) return ORBHIP_ERR_STATE;
     const PlanDev& P = e->plan;
     const LevelGeom& g = P.lv[level];
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     HIP_TRY(e, hipDeviceSynchronize());
     const Workspace& W = e->ws[e->last_ws];
     int n = 0;
@@ -1186,7 +1435,7 @@ int orbhip_enable_timing(orbhip_extractor* e, int on) {
 
 int orbhip_get_timing(orbhip_extractor* e, const char** names, float* ms, int* launches, int cap) {
     if (!e) return ORBHIP_ERR_ARG;
-    (void)hipSetDevice(e->device);
+    DeviceScope device_scope(e->device);
     (void)hipDeviceSynchronize();
     collect_timing(e);
     for (int i = 0; i < KC_COUNT && i < cap; i++) {
@@ -1206,6 +1455,10 @@ static int stereo_batch_check(orbhip_extractor* left, orbhip_extractor* right, i
         cap < 1 || cap > 65535 || nframes < 1 || !(mb > 0.f))
         return ORBHIP_ERR_ARG;
     orbhip_extractor* e = left;
+    if (left == right) {
+        e->err = "left and right must be two instances (each keeps the pyramids of its own side)";
+        return ORBHIP_ERR_ARG;
+    }
     if (!left->plan_w || !right->plan_w || nframes > left->last_pass_frames || nframes > right->last_pass_frames) {
         e->err = "stereo matching needs a pass of at least nframes frames on both instances";
         return ORBHIP_ERR_STATE;
@@ -1309,7 +1562,7 @@ int orbhip_stereo_match_batch_device(orbhip_extractor* left, orbhip_extractor* r
     int rc = stereo_batch_check(left, right, nframes, d_kp_l, d_desc_l, d_cnt_l, d_kp_r, d_desc_r, d_cnt_r, cap, mb, d_uright, d_depth);
     if (rc) return rc;
     orbhip_extractor* e = left;
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     rc = stereo_scratch(left, nframes, cap);
     if (rc) return rc;
@@ -1333,7 +1586,7 @@ int orbhip_stereo_match_batch_device_noalloc(orbhip_extractor* left, orbhip_extr
         return ORBHIP_ERR_CAPACITY;
     }
     if (!e->noalloc_scratch) { e->err = "static scratch address unknown"; return ORBHIP_ERR_STATE; }
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     // carve the device's copy of the static array (its address, not the symbol's name)
     unsigned char* base = static_cast<unsigned char*>(e->noalloc_scratch);
@@ -1356,6 +1609,10 @@ int orbhip_extract_stereo_batch_device(orbhip_extractor* left, orbhip_extractor*
     if (!d_imgs_l || !d_imgs_r || width <= 0 || height <= 0 || nframes == 0) return ORBHIP_ERR_EMPTY;
     if (row_stride < (size_t)width) return ORBHIP_ERR_ARG;
     orbhip_extractor* e = left;
+    if (left == right) {
+        e->err = "left and right must be two instances (the right pass would overwrite the left pyramids before they are matched)";
+        return ORBHIP_ERR_ARG;
+    }
     if (left->device != right->device || left->prm.nlevels != right->prm.nlevels || left->prm.scale_factor != right->prm.scale_factor) {
         e->err = "left and right instances differ in device or pyramid parameters";
         return ORBHIP_ERR_ARG;
@@ -1366,7 +1623,7 @@ int orbhip_extract_stereo_batch_device(orbhip_extractor* left, orbhip_extractor*
             e->err = "rectification maps are set: the input must be a gray image of the maps' size";
             return ORBHIP_ERR_ARG;
         }
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     for (orbhip_extractor* x : sides) {
         if (x->last_stream && x->last_stream != s) HIP_TRY(e, hipStreamWaitEvent(s, x->ev_busy, 0));
@@ -1419,7 +1676,7 @@ int orbhip_stereo_match(orbhip_extractor* left, orbhip_extractor* right,
     if (n_l == 0) { if (nmatch) *nmatch = 0; return ORBHIP_OK; }
     if (!kp_l || !desc_l || (n_r > 0 && (!kp_r || !desc_r))) return ORBHIP_ERR_ARG;
     orbhip_extractor* e = left;
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     const int cap = std::max(std::max(n_l, n_r), 1);
     const size_t kpb = (size_t)cap * sizeof(orbhip_keypoint), db = (size_t)cap * 32, fb = (size_t)cap * sizeof(float);
     const size_t need = 2 * kpb + 2 * db + 2 * fb + 64;
@@ -1456,6 +1713,115 @@ int orbhip_stereo_match(orbhip_extractor* left, orbhip_extractor* right,
     return ORBHIP_OK;
 }
 
+int orbhip_extract_stereo_batch(orbhip_extractor* left, orbhip_extractor* right, const uint8_t* imgs_l, const uint8_t* imgs_r,
+                                int npairs, int width, int height, size_t row_stride, size_t frame_stride,
+                                orbhip_keypoint* kp_l, uint8_t* desc_l, int* cnt_l, orbhip_keypoint* kp_r, uint8_t* desc_r, int* cnt_r,
+                                int cap, float mb, float mbf, float* uright, float* depth, int* nmatch) {
+    if (!left || !right || left == right || !kp_l || !desc_l || !cnt_l || !kp_r || !desc_r || !cnt_r || !uright || !depth ||
+        cap < 1 || cap > 65535 || npairs < 0 || !(mb > 0.f))
+        return ORBHIP_ERR_ARG;
+    if (!imgs_l || !imgs_r || width <= 0 || height <= 0 || npairs == 0) return ORBHIP_ERR_EMPTY;
+    if (row_stride < (size_t)width) return ORBHIP_ERR_ARG;
+    orbhip_extractor* e = left;
+    if (left->device != right->device) { e->err = "left and right instances live on different devices"; return ORBHIP_ERR_ARG; }
+    DEVICE_SCOPE(e);
+    const size_t dev_row = ((size_t)width + 15) & ~(size_t)15, dev_frame = dev_row * height;
+    HostStage hl, hr;
+    int rc = host_staging(left, dev_frame * npairs, true, npairs, cap, &hl);
+    if (rc) return rc;
+    rc = host_staging(right, dev_frame * npairs, true, npairs, cap, &hr);
+    if (rc) { e->err = right->err; return rc; }
+    // mvuRight, mvDepth and the match count per pair: device arrays and their pinned copy, owned by the left instance
+    const size_t fl_bytes = (size_t)npairs * cap * sizeof(float), nm_bytes = ((size_t)npairs * sizeof(int) + 15) & ~(size_t)15;
+    const size_t st_bytes = 2 * fl_bytes + nm_bytes;
+    if (st_bytes > e->st_host_bytes) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        dfree(e->d_st_host);
+        if (e->h_st_host) (void)hipHostFree(e->h_st_host);
+        e->h_st_host = nullptr; e->st_host_bytes = 0;
+        HIP_TRY(e, hipMalloc(&e->d_st_host, st_bytes));
+        HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_st_host), st_bytes, hipHostMallocDefault));
+        e->st_host_bytes = st_bytes;
+    }
+    float* d_ur = reinterpret_cast<float*>(e->d_st_host);
+    float* d_dep = reinterpret_cast<float*>(e->d_st_host + fl_bytes);
+    int* d_nm = reinterpret_cast<int*>(e->d_st_host + 2 * fl_bytes);
+    hipStream_t s = e->stream;
+    orbhip_extractor* const sides[2] = {left, right};
+    const uint8_t* const imgs[2] = {imgs_l, imgs_r};
+    for (int k = 0; k < 2; k++) {
+        pack_frames(imgs[k], row_stride, frame_stride, sides[k]->h_in, dev_row, height, (size_t)width, npairs);
+        HIP_TRY(e, hipMemcpyAsync(sides[k]->d_in, sides[k]->h_in, dev_frame * npairs, hipMemcpyHostToDevice, s));
+    }
+    rc = orbhip_extract_stereo_batch_device(left, right, left->d_in, right->d_in, npairs, width, height, dev_row, dev_frame,
+                                            reinterpret_cast<orbhip_keypoint*>(left->d_out_kp), left->d_out_desc, left->d_out_cnt,
+                                            reinterpret_cast<orbhip_keypoint*>(right->d_out_kp), right->d_out_desc, right->d_out_cnt, cap,
+                                            mb, mbf, d_ur, d_dep, d_nm, s);
+    if (rc) { (void)hipDeviceSynchronize(); return rc; }
+    const HostStage* const hs[2] = {&hl, &hr};
+    for (int k = 0; k < 2; k++) {
+        HIP_TRY(e, hipMemcpyAsync(hs[k]->h_cnt, sides[k]->d_out_cnt, (size_t)npairs * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipMemcpyAsync(hs[k]->h_kp, sides[k]->d_out_kp, hs[k]->kp_bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipMemcpyAsync(hs[k]->h_desc, sides[k]->d_out_desc, hs[k]->desc_bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipMemcpyAsync(hs[k]->h_status, sides[k]->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(e, hipMemcpyAsync(e->h_st_host, e->d_st_host, st_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    collect_timing(left); collect_timing(right);
+    rc = host_status(left, hl, s);
+    if (rc) return rc;
+    rc = host_status(right, hr, s);
+    if (rc) { e->err = right->err; return rc; }
+    unpack_frames(hl, 0, npairs, cap, kp_l, desc_l, cnt_l);
+    unpack_frames(hr, 0, npairs, cap, kp_r, desc_r, cnt_r);
+    const float* h_ur = reinterpret_cast<const float*>(e->h_st_host);
+    const float* h_dep = reinterpret_cast<const float*>(e->h_st_host + fl_bytes);
+    for (int f = 0; f < npairs; f++) {
+        const int m = std::min(cnt_l[f], cap);
+        if (m <= 0) continue;
+        std::memcpy(uright + (size_t)f * cap, h_ur + (size_t)f * cap, (size_t)m * sizeof(float));
+        std::memcpy(depth + (size_t)f * cap, h_dep + (size_t)f * cap, (size_t)m * sizeof(float));
+    }
+    if (nmatch) std::memcpy(nmatch, e->h_st_host + 2 * fl_bytes, (size_t)npairs * sizeof(int));
+    return ORBHIP_OK;
+}
+
+int orbhip_extract_stereo_batch_multi(orbhip_extractor* const* left, orbhip_extractor* const* right, int nhandles,
+                                      const uint8_t* imgs_l, const uint8_t* imgs_r, int npairs, int width, int height,
+                                      size_t row_stride, size_t frame_stride,
+                                      orbhip_keypoint* kp_l, uint8_t* desc_l, int* cnt_l, orbhip_keypoint* kp_r, uint8_t* desc_r, int* cnt_r,
+                                      int cap, float mb, float mbf, float* uright, float* depth, int* nmatch) {
+    if (!left || !right || nhandles < 1 || npairs < 0 || cap < 1) return ORBHIP_ERR_ARG;
+    for (int i = 0; i < nhandles; i++) {
+        if (!left[i] || !right[i]) return ORBHIP_ERR_ARG;
+        for (int j = 0; j < i; j++)
+            if (left[j] == left[i] || right[j] == right[i] || left[j] == right[i] || right[j] == left[i]) return ORBHIP_ERR_ARG;
+    }
+    if (!imgs_l || !imgs_r || width <= 0 || height <= 0 || npairs == 0) return ORBHIP_ERR_EMPTY;
+    // both images of a pair go to the same pair of handles (the matcher reads both pyramids on one device)
+    std::vector<int> rcs((size_t)nhandles, ORBHIP_OK);
+    auto work = [&](int i) {
+        int lo = 0, hi = 0;
+        orbhip_shard_range(npairs, nhandles, i, 1, &lo, &hi);
+        if (hi <= lo) return;
+        const size_t o = (size_t)lo * cap;
+        rcs[(size_t)i] = orbhip_extract_stereo_batch(left[i], right[i], imgs_l + (size_t)lo * frame_stride, imgs_r + (size_t)lo * frame_stride,
+                                                     hi - lo, width, height, row_stride, frame_stride, kp_l + o, desc_l + o * 32, cnt_l + lo,
+                                                     kp_r + o, desc_r + o * 32, cnt_r + lo, cap, mb, mbf, uright + o, depth + o,
+                                                     nmatch ? nmatch + lo : nullptr);
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < nhandles; i++) th.emplace_back(work, i);
+    work(0);
+    for (std::thread& t : th) t.join();
+    for (int i = 0; i < nhandles; i++)
+        if (rcs[(size_t)i]) {
+            if (i) left[0]->err = "handle pair " + std::to_string(i) + ": " + left[i]->err;
+            return rcs[(size_t)i];
+        }
+    return ORBHIP_OK;
+}
+
 int orbhip_image_bounds(const orbhip_camera* cam, int width, int height, float bounds[4]) {
     if (!cam || !bounds || width < 1 || height < 1) return ORBHIP_ERR_ARG;
     if (cam->k1 != 0.0f) {                                     // src/Frame.cc:453-470
@@ -1477,7 +1843,7 @@ int orbhip_stereo_from_rgbd_batch_device(orbhip_extractor* e, int nframes, const
     if (!e || nframes < 1 || cap < 1 || !d_kp || !d_kp_un || !d_counts || !d_depth || width < 1 || height < 1 || !d_uright || !d_depth_out ||
         row_stride < (size_t)width * (depth_is_u16 ? 2 : 4))
         return ORBHIP_ERR_ARG;
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     // src/Tracking.cc (GrabImageRGBD): the map is converted when the factor is not 1 or the type is not CV_32F
     const int convert = (std::fabs(depth_map_factor - 1.0f) > 1e-5) || depth_is_u16;
@@ -1494,7 +1860,7 @@ int orbhip_unproject_stereo_batch_device(orbhip_extractor* e, int nframes, const
     if (!e || nframes < 1 || cap < 1 || !d_kp_un || !d_depth || !d_counts || !d_pose_wc || !d_world || !d_valid || !(fx != 0.0f) ||
         !(fy != 0.0f))
         return ORBHIP_ERR_ARG;
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     const float invfx = 1.0f / fx, invfy = 1.0f / fy;          // src/Frame.cc: invfx = 1.0f/fx in the constructors
     hipLaunchKernelGGL(k_unproject_stereo, dim3((cap + 255) / 256, nframes), dim3(256), 0, s, reinterpret_cast<const GridKp*>(d_kp_un),
@@ -1510,7 +1876,7 @@ int orbhip_undistort_grid_batch_device(orbhip_extractor* e, int nframes, const o
     if (!e || nframes < 1 || !d_kp || !d_counts || cap < 1 || !cam || !bounds || !d_kp_un || !d_grid_start || !d_grid_idx ||
         !(bounds[1] > bounds[0]) || !(bounds[3] > bounds[2]))
         return ORBHIP_ERR_ARG;
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     const CamDev c = {cam->fx, cam->fy, cam->cx, cam->cy, cam->k1, cam->k2, cam->p1, cam->p2, cam->k3};
     // mfGridElementWidthInv / mfGridElementHeightInv (src/Frame.cc:128-129)
@@ -1525,7 +1891,7 @@ int orbhip_undistort_grid_batch_device(orbhip_extractor* e, int nframes, const o
 int orbhip_undistort_grid(orbhip_extractor* e, const orbhip_keypoint* kp, int n, const orbhip_camera* cam,
                           const float bounds[4], orbhip_keypoint* kp_un, int* grid_start, int* grid_idx) {
     if (!e || n < 0 || !cam || !bounds || !grid_start || (n > 0 && (!kp || !kp_un || !grid_idx))) return ORBHIP_ERR_ARG;
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     const int cap = std::max(n, 1);
     const size_t kpb = (size_t)cap * sizeof(orbhip_keypoint), gsb = (size_t)(GRID_CELLS + 1) * sizeof(int), gib = (size_t)cap * sizeof(int);
     const size_t need = 64 + 2 * kpb + gsb + gib;
@@ -1566,7 +1932,7 @@ int orbhip_search_for_initialization_batch_device(orbhip_extractor* e, int nfram
         return ORBHIP_ERR_ARG;
     const size_t lds = (size_t)MT_LDS_PER_KP * cap + 16;
     if (lds > 160 * 1024 - 512) { e->err = "too many keypoints per frame for the on-chip matcher state"; return ORBHIP_ERR_CAPACITY; }
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     const float inv_w = static_cast<float>(GRID_COLS) / (bounds[1] - bounds[0]);
     const float inv_h = static_cast<float>(GRID_ROWS) / (bounds[3] - bounds[2]);
@@ -1598,7 +1964,7 @@ int orbhip_search_for_initialization(orbhip_extractor* e, const orbhip_keypoint*
     if (!e || n1 < 0 || n2 < 0 || !bounds || !nmatches) return ORBHIP_ERR_ARG;
     if (n1 == 0) { *nmatches = 0; return ORBHIP_OK; }
     if (!kp_un1 || !desc1 || !prev_matched || !matches12 || (n2 > 0 && (!kp_un2 || !desc2))) return ORBHIP_ERR_ARG;
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     const int cap = std::max(std::max(n1, n2), 1);
     const size_t kpb = (size_t)cap * sizeof(orbhip_keypoint), db = (size_t)cap * 32;
     const size_t pb = (size_t)cap * 2 * sizeof(float), mb = (size_t)cap * sizeof(int);
@@ -1639,7 +2005,7 @@ int orbhip_search_for_initialization(orbhip_extractor* e, const orbhip_keypoint*
 
 int orbhip_set_rectification(orbhip_extractor* e, const float* map_x, const float* map_y, int width, int height) {
     if (!e) return ORBHIP_ERR_ARG;
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     HIP_TRY(e, hipDeviceSynchronize());                        // no pass may still read the old maps
     e->config_gen++;                                           // a captured graph holds the old maps (or none)
     dfree(e->d_map_x); dfree(e->d_map_y);
@@ -1657,7 +2023,7 @@ int orbhip_set_rectification(orbhip_extractor* e, const float* map_x, const floa
 
 int orbhip_debug_sincos(orbhip_extractor* e, uint32_t first_bits, uint32_t count, float* d_cos, float* d_sin, void* stream) {
     if (!e || !d_cos || !d_sin || count == 0 || count > (1u << 30)) return ORBHIP_ERR_ARG;
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     hipLaunchKernelGGL(k_debug_sincos, dim3((count + 255u) / 256u), dim3(256), 0, s, first_bits, count, d_cos, d_sin);
     HIP_TRY(e, hipGetLastError());
@@ -1709,7 +2075,7 @@ int orbhip_search_by_projection_batch_device(orbhip_extractor* e, int nframes, i
         return ORBHIP_ERR_ARG;
     const size_t lds = (size_t)MP_LDS_PER_KP * cap + 16;
     const bool spill = lds > 160 * 1024 - 20 * 1024;                // the state then lives in global memory
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     if (!spill && lds > 40 * 1024)
         HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_proj<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1748,7 +2114,7 @@ int orbhip_search_by_projection(orbhip_extractor* e, const orbhip_keypoint* kp_l
     for (int i = 0; i < n2; i++) match_cur[i] = -1;
     if (n1 == 0 || n2 == 0) { *nmatches = 0; return ORBHIP_OK; }
     if (!kp_last || !world_last || !flags_last || !desc_last || !kp_cur || !desc_cur) return ORBHIP_ERR_ARG;
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     const int cap = std::max(n1, n2);
     auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
     const size_t kpb = up((size_t)cap * sizeof(orbhip_keypoint)), db = up((size_t)cap * 32), wb = up((size_t)cap * 12);
@@ -1805,7 +2171,7 @@ int orbhip_search_by_projection_keyframe_batch_device(orbhip_extractor* e, int n
         return ORBHIP_ERR_ARG;
     const size_t lds = (size_t)MP_LDS_PER_KP * cap + 16;
     const bool spill = lds > 160 * 1024 - 20 * 1024;                // the state then lives in global memory
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     if (!spill && lds > 40 * 1024)
         HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_proj<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1859,7 +2225,7 @@ int orbhip_search_by_projection_sim3_batch_device(orbhip_extractor* e, int nfram
         return ORBHIP_ERR_ARG;
     const size_t lds = (size_t)MP_LDS_PER_KP * cap + 16;
     const bool spill = lds > 160 * 1024 - 20 * 1024;                // the state then lives in global memory
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     if (!spill && lds > 40 * 1024)
         HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_proj<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1901,7 +2267,7 @@ int orbhip_search_by_projection_sim3(orbhip_extractor* e, const float* world, co
     if (!world || !normal || !dist_range || !flags || !desc || !kp_kf || !desc_kf) return ORBHIP_ERR_ARG;
     float Tcw[12];
     orbhip_decompose_sim3(Scw, Tcw);
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     const int cap = std::max(n1, n2);
     auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
     const size_t kpb = up((size_t)cap * sizeof(orbhip_keypoint)), db = up((size_t)cap * 32), wb = up((size_t)cap * 12);
@@ -1956,7 +2322,7 @@ int orbhip_search_by_projection_keyframe(orbhip_extractor* e, const orbhip_keypo
     for (int i = 0; i < n2; i++) match_cur[i] = -1;
     if (n1 == 0 || n2 == 0) { *nmatches = 0; return ORBHIP_OK; }
     if (!kp_kf || !world_kf || !dist_range_kf || !flags_kf || !desc_kf || !kp_cur || !desc_cur) return ORBHIP_ERR_ARG;
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     const int cap = std::max(n1, n2);
     auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
     const size_t kpb = up((size_t)cap * sizeof(orbhip_keypoint)), db = up((size_t)cap * 32), wb = up((size_t)cap * 12);
@@ -2013,7 +2379,7 @@ static int search_by_bow_launch(orbhip_extractor* e, bool kfkf, int nframes, int
     if (cap > 65535) { e->err = "the bag-of-words matcher indexes features with 16 bits (cap <= 65535)"; return ORBHIP_ERR_CAPACITY; }
     int npad = 64;
     while (npad < cap) npad <<= 1;
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     const GridKp* k1 = reinterpret_cast<const GridKp*>(d_kp1);
     const GridKp* k2 = reinterpret_cast<const GridKp*>(d_kp2);
@@ -2072,7 +2438,7 @@ static int search_by_bow_host(orbhip_extractor* e, bool kfkf, const orbhip_keypo
     for (int i = 0; i < nout; i++) match[i] = -1;
     if (n1 == 0 || n2 == 0) { *nmatches = 0; return ORBHIP_OK; }
     if (!kp1 || !desc1 || !node1 || !flags1 || !kp2 || !desc2 || !node2 || (kfkf && !flags2)) return ORBHIP_ERR_ARG;
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     const int cap = std::max(n1, n2);
     auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
     const size_t kpb = up((size_t)cap * sizeof(orbhip_keypoint)), db = up((size_t)cap * 32), nb = up((size_t)cap * 4), fb = up((size_t)cap);
@@ -2140,7 +2506,7 @@ int orbhip_search_map_points_batch_device(orbhip_extractor* e, int nframes, int 
     static_assert(sizeof(orbhip_track_point) == sizeof(TrackPt), "track point layout");
     const size_t lds = (size_t)ML_LDS_PER_MP * cap_mp + (size_t)ML_LDS_PER_KP * cap_kp + 32;
     const bool spill = lds > 160 * 1024 - 20 * 1024;                // the state then lives in global memory
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     if (!spill && lds > 40 * 1024)
         HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_map<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2173,7 +2539,7 @@ int orbhip_search_map_points(orbhip_extractor* e, const orbhip_track_point* mp, 
     for (int i = 0; i < n2; i++) match[i] = -1;
     if (n1 == 0 || n2 == 0) { *nmatches = 0; return ORBHIP_OK; }
     if (!mp || !desc_mp || !kp || !desc) return ORBHIP_ERR_ARG;
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
     const size_t tb = up((size_t)n1 * sizeof(orbhip_track_point)), d1b = up((size_t)n1 * 32);
     const size_t kpb = up((size_t)n2 * sizeof(orbhip_keypoint)), d2b = up((size_t)n2 * 32), ub = up((size_t)n2 * 4), ob = up((size_t)n2);
@@ -2215,7 +2581,7 @@ int orbhip_debug_logf(orbhip_extractor* e, uint32_t first_bits, uint32_t count, 
     if (!e || !d_out || count == 0 || count > (1u << 30) || stride == 0) return ORBHIP_ERR_ARG;
     const unsigned long long last = (unsigned long long)first_bits + (unsigned long long)(count - 1) * stride;
     if (first_bits < 0x00800000u || last >= 0x7f800000ull) return ORBHIP_ERR_ARG;   // positive normal floats only
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     hipLaunchKernelGGL(k_debug_logf, dim3((count + 255u) / 256u), dim3(256), 0, s, first_bits, count, stride, d_out);
     HIP_TRY(e, hipGetLastError());
@@ -2227,7 +2593,7 @@ int orbhip_is_in_frustum_batch_device(orbhip_extractor* e, int nframes, int cap_
                                       orbhip_track_point* d_track, int* d_nvisible, void* stream) {
     if (!e || nframes < 1 || cap_mp < 1 || !d_mp || !d_cnt_mp || !d_pose || !prm || !d_track) return ORBHIP_ERR_ARG;
     static_assert(sizeof(orbhip_map_point) == sizeof(MapPt), "map point layout");
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     FrustumArgs a;
     a.fx = prm->fx; a.fy = prm->fy; a.cx = prm->cx; a.cy = prm->cy; a.mbf = prm->mbf;
@@ -2248,7 +2614,7 @@ int orbhip_is_in_frustum(orbhip_extractor* e, const orbhip_map_point* mp, int n,
     if (nvisible) *nvisible = 0;
     if (n == 0) return ORBHIP_OK;
     if (!mp || !track) return ORBHIP_ERR_ARG;
-    HIP_TRY(e, hipSetDevice(e->device));
+    DEVICE_SCOPE(e);
     auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
     const size_t mb = up((size_t)n * sizeof(orbhip_map_point)), tb = up((size_t)n * sizeof(orbhip_track_point));
     const size_t need = 128 + mb + tb;

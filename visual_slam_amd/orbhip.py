@@ -42,6 +42,7 @@ EXPORTS = [
     "orbhip_search_by_projection_keyframe", "orbhip_search_by_projection_keyframe_batch_device",
     "orbhip_search_by_bow", "orbhip_search_by_bow_batch_device",
     "orbhip_search_by_bow_keyframes", "orbhip_search_by_bow_keyframes_batch_device",
+    "orbhip_extract_batch_multi", "orbhip_shard_range", "orbhip_extract_stereo_batch", "orbhip_extract_stereo_batch_multi",
     "orbhip_stereo_from_rgbd_batch_device", "orbhip_unproject_stereo_batch_device", "orbhip_decompose_sim3", "orbhip_search_by_projection_sim3", "orbhip_search_by_projection_sim3_batch_device",
 ]
 
@@ -137,6 +138,12 @@ def lib():
         L.orbhip_stereo_match_batch_device_noalloc.argtypes = L.orbhip_stereo_match_batch_device.argtypes
         L.orbhip_extract_stereo_batch_device.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
                                                          vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, vp, vp]
+        L.orbhip_extract_batch_multi.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, vp, vp, vp, C.c_int]
+        L.orbhip_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, ip, ip]
+        L.orbhip_extract_stereo_batch.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
+                                                  vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, vp]
+        L.orbhip_extract_stereo_batch_multi.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
+                                                        vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -407,6 +414,56 @@ def extract_stereo_batch_device(left, right, d_imgs_l, d_imgs_r, nframes, w, h, 
     left._check(lib().orbhip_extract_stereo_batch_device(left._h, right._h, d_imgs_l, d_imgs_r, nframes, w, h, row_stride, frame_stride,
                                                          d_kp_l, d_desc_l, d_cnt_l, d_kp_r, d_desc_r, d_cnt_r, cap, mb, mbf,
                                                          d_uright, d_depth, d_nmatch, stream))
+
+
+def shard_range(nframes, nshards, index, group=1):
+    """[lo, hi) of the frames shard `index` owns (orbhip_shard_range: the partition the multi-handle calls use)."""
+    lo, hi = C.c_int(), C.c_int()
+    rc = lib().orbhip_shard_range(nframes, nshards, index, group, C.byref(lo), C.byref(hi))
+    if rc:
+        raise OrbHipError(rc)
+    return lo.value, hi.value
+
+
+def extract_batch_multi(extractors, images):
+    """operator() over a (F,H,W) uint8 host array, the frames sharded over several handles (one per GPU, or
+    several on one GPU), one host thread per handle inside the library. Returns the per-frame results in order."""
+    images = np.ascontiguousarray(images, np.uint8)
+    f, h, w = images.shape
+    cap = extractors[0].max_keypoints(w, h)
+    kp = np.zeros((f, cap), KP_DTYPE)
+    desc = np.zeros((f, cap, 32), np.uint8)
+    counts = np.zeros(f, np.int32)
+    handles = (C.c_void_p * len(extractors))(*[x._h for x in extractors])
+    extractors[0]._check(lib().orbhip_extract_batch_multi(handles, len(extractors), _ptr(images), f, w, h, images.strides[1],
+                                                          images.strides[0], _ptr(kp), _ptr(desc), _ptr(counts), cap))
+    return [(kp[i, :counts[i]].copy(), desc[i, :counts[i]].copy()) for i in range(f)]
+
+
+def extract_stereo_batch(left, right, images_l, images_r, mb, mbf):
+    """Both extractions and Frame::ComputeStereoMatches for (P,H,W) host arrays of rectified pairs. `left` / `right` are
+    one instance each, or equally long lists of instances (pairs sharded over them). Returns per pair
+    (kp_l, desc_l, kp_r, desc_r, mvuRight, mvDepth, matches)."""
+    images_l = np.ascontiguousarray(images_l, np.uint8); images_r = np.ascontiguousarray(images_r, np.uint8)
+    assert images_l.shape == images_r.shape
+    p, h, w = images_l.shape
+    multi = isinstance(left, (list, tuple))
+    first = left[0] if multi else left
+    cap = first.max_keypoints(w, h)
+    kl, kr = np.zeros((p, cap), KP_DTYPE), np.zeros((p, cap), KP_DTYPE)
+    dl, dr = np.zeros((p, cap, 32), np.uint8), np.zeros((p, cap, 32), np.uint8)
+    cl, cr, nm = np.zeros(p, np.int32), np.zeros(p, np.int32), np.zeros(p, np.int32)
+    ur, dep = np.full((p, cap), -1.0, np.float32), np.full((p, cap), -1.0, np.float32)
+    tail = (_ptr(images_l), _ptr(images_r), p, w, h, images_l.strides[1], images_l.strides[0], _ptr(kl), _ptr(dl), _ptr(cl),
+            _ptr(kr), _ptr(dr), _ptr(cr), cap, mb, mbf, _ptr(ur), _ptr(dep), _ptr(nm))
+    if multi:
+        hl = (C.c_void_p * len(left))(*[x._h for x in left])
+        hr = (C.c_void_p * len(right))(*[x._h for x in right])
+        first._check(lib().orbhip_extract_stereo_batch_multi(hl, hr, len(left), *tail))
+    else:
+        first._check(lib().orbhip_extract_stereo_batch(left._h, right._h, *tail))
+    return [(kl[i, :cl[i]].copy(), dl[i, :cl[i]].copy(), kr[i, :cr[i]].copy(), dr[i, :cr[i]].copy(),
+             ur[i, :cl[i]].copy(), dep[i, :cl[i]].copy(), int(nm[i])) for i in range(p)]
 
 
 class ORBextractor:
