@@ -99,7 +99,7 @@ int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int 
  * `nframes` images in host memory; waits for the results. Batches of 8 frames and more run as a pipeline of
  * chunks (about 64 MB of images each, ORBHIP_HOST_CHUNK=n frames overrides) over three internal streams and
  * workspaces: while one chunk is packed into page-locked memory by a few host threads (ORBHIP_PACK_THREADS,
- * default half of the CPUs the process may use, at most 8), the previous one travels to the device, the one
+ * default half of the CPUs the process may use, at most 4), the previous one travels to the device, the one
  * before is extracted and the results of the one before that travel back. Images that already lie in
  * page-locked memory (hipHostMalloc / hipHostRegister) are copied from where they are, without the packing
  * step. ORBHIP_HOST_PIPELINE=0 (read by orbhip_create) restores one copy up, all passes, one copy down.

@@ -27,17 +27,21 @@ def test_two_instances_on_two_threads_like_stereo():
     from visual_slam_amd import orbhip
     left, right = synth.frame("blocks", 1241, 376, 21), synth.frame("blocks", 1241, 376, 22)
     exl, exr = orbhip.ORBextractor(2000, 1.2, 8, 20, 7), orbhip.ORBextractor(2000, 1.2, 8, 20, 7)
-    res = {}
+    res, errors = {}, []
 
     def work(name, ex, img):
-        for _ in range(5):
-            res[name] = ex(img)
+        try:
+            for _ in range(8):                                   # (the second call captures a graph, later ones replay it)
+                res[name] = ex(img)
+        except Exception as exc:                                 # an exception in a thread would otherwise pass unseen
+            errors.append((name, repr(exc)))
 
     th = [threading.Thread(target=work, args=("l", exl, left)), threading.Thread(target=work, args=("r", exr, right))]
     for t in th:
         t.start()
     for t in th:
         t.join()
+    assert not errors, errors
     o = O.OracleExtractor(2000, 1.2, 8, 20, 7)
     for name, img, ex in (("l", left, exl), ("r", right, exr)):
         okp, odesc = o.extract(img)

@@ -151,11 +151,12 @@ struct orbhip_extractor {
     unsigned long long h_pyr_gen = 0;
     int h_pyr_frame = -1;
     // The single-frame host call (what a SLAM front end makes per camera frame) is launch-bound: its copy up,
-    // its kernel launches and its copies down are captured into a HIP graph the second time a configuration
+    // (behind the copy up, which goes band by band as the image is packed) its kernel launches and its copies down are captured into a HIP graph the second time a configuration
     // is seen and replayed from then on (ORBHIP_GRAPH=0: never). config_gen counts everything that
     // invalidates the captured pointers: a new plan, new staging buffers, new rectification maps.
     int use_graph = 1;
     int host_pipeline = 1;         // ORBHIP_HOST_PIPELINE=0: the host batch call runs as one copy up, all passes, one copy down
+    int host_lanes = 3;            // ORBHIP_HOST_LANES=2..4: chunks of the pipelined host batch call in flight
     int host_chunk = 0;            // ORBHIP_HOST_CHUNK=n: frames per chunk of the pipelined host batch call (0: about 64 MB of images)
     hipGraphExec_t graph_exec = nullptr;
     struct GraphKey { int w, h, channels, rgb, cap; unsigned long long gen; } graph_key = {0, 0, 0, 0, 0, 0}, graph_seen = {0, 0, 0, 0, 0, 0};
@@ -772,6 +773,7 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
     if (const char* v = std::getenv("ORBHIP_GRAPH")) e->use_graph = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_HOST_PIPELINE")) e->host_pipeline = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_HOST_CHUNK")) e->host_chunk = std::max(0, std::atoi(v));
+    if (const char* v = std::getenv("ORBHIP_HOST_LANES")) e->host_lanes = std::min(kLanes, std::max(2, std::atoi(v)));
     if (const char* v = std::getenv("ORBHIP_QT_LDS_LIMIT")) e->qt_lds_limit = std::min<size_t>(160 * 1024 - 256, (size_t)std::max(std::atoi(v), 1024));
     *out = e;
     return ORBHIP_OK;
@@ -897,7 +899,7 @@ int orbhip_synchronize(orbhip_extractor* e) {
 }
 
 // Worker threads for packing a chunk of caller images into pinned memory: half of the CPUs this process may
-// run on, at most 8 (ORBHIP_PACK_THREADS overrides; a GPU box reports the whole machine in
+// run on, at most 4 (ORBHIP_PACK_THREADS overrides; a GPU box reports the whole machine in
 // hardware_concurrency, the affinity mask is what the process really has).
 static int pack_threads() {
     static const int n = [] {
@@ -905,7 +907,7 @@ static int pack_threads() {
         int c = 1;
         cpu_set_t set;
         if (sched_getaffinity(0, sizeof set, &set) == 0) c = CPU_COUNT(&set);
-        return std::max(1, std::min(c / 2, 8));
+        return std::max(1, std::min(c / 2, 4));
     }();
     return n;
 }
@@ -1037,7 +1039,7 @@ static int extract_host_pipelined(orbhip_extractor* e, const uint8_t* imgs, int 
     chunk = std::min(chunk, (nframes + 3) / 4);                // four chunks at least, so that the stages overlap
     chunk = std::max(1, std::min(chunk, budget));
     const int nchunks = (nframes + chunk - 1) / chunk;
-    const int nl = std::min(3, nchunks);
+    const int nl = std::min(e->host_lanes, nchunks);
     const bool pinned = host_pointer_is_pinned(imgs);
     HostStage hs;
     int rc = host_staging(e, (size_t)nl * chunk * dev_frame, !pinned, nframes, cap, &hs);
@@ -1091,13 +1093,11 @@ static int extract_host_pipelined(orbhip_extractor* e, const uint8_t* imgs, int 
         st = hipMemcpyAsync(hs.h_cnt + (size_t)f0 * sizeof(int), e->d_out_cnt + f0, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s);
         if (st == hipSuccess) st = hipMemcpyAsync(hs.h_kp + o * sizeof(orbhip_keypoint), e->d_out_kp + o * 7, (size_t)n * cap * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, s);
         if (st == hipSuccess) st = hipMemcpyAsync(hs.h_desc + o * 32, e->d_out_desc + o * 32, (size_t)n * cap * 32, hipMemcpyDeviceToHost, s);
-        if (st == hipSuccess && k == nchunks - 1) st = hipMemcpyAsync(hs.h_status, e->d_status, sizeof(int), hipMemcpyDeviceToHost, s);
         if (st == hipSuccess) st = hipEventRecord(W.done, s);
         if (st != hipSuccess) { e->err = std::string("copy of a chunk's results: ") + hipGetErrorString(st); return fail(ORBHIP_ERR_HIP); }
         last = s;
     }
-    // (the status word was read behind the last chunk's results, but chunks overlap: drain the other lanes before trusting it)
-    HIP_TRY(e, hipDeviceSynchronize());
+    // every chunk's results are down (the loop waited for each lane's event): the status word of the whole batch
     HIP_TRY(e, hipMemcpyAsync(hs.h_status, e->d_status, sizeof(int), hipMemcpyDeviceToHost, last));
     HIP_TRY(e, hipStreamSynchronize(last));
     e->last_stream = last;
@@ -1122,8 +1122,27 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
     int rc = host_staging(e, need, true, nframes, cap, &hs);
     if (rc) return rc;
     const size_t kp_bytes = hs.kp_bytes, desc_bytes = hs.desc_bytes;
-    // pack the rows into the pinned buffer (a 2-D copy from pageable memory would go row by row)
-    pack_frames(imgs, row_stride, frame_stride, e->h_in, dev_row, height, (size_t)width * channels, nframes);
+    // Images up, in row bands of about half a megabyte: a band travels while the next one is packed into the
+    // page-locked buffer (one thread packs a camera frame in about the time its copy takes; a 2-D copy from
+    // pageable memory would go row by row). Images that lie in page-locked memory are copied from there.
+    if (e->last_stream && e->last_stream != e->stream) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_busy, 0));
+    e->last_stream = e->stream;
+    {
+        const size_t width_bytes = (size_t)width * channels;
+        if (host_pointer_is_pinned(imgs)) {
+            for (int f = 0; f < nframes; f++)
+                HIP_TRY(e, hipMemcpy2DAsync(e->d_in + (size_t)f * dev_frame, dev_row, imgs + (size_t)f * frame_stride, row_stride, width_bytes,
+                                            (size_t)height, hipMemcpyHostToDevice, e->stream));
+        } else {
+            const size_t rows = (size_t)nframes * (size_t)height;
+            const size_t band = std::max<size_t>(16, ((size_t)512 << 10) / dev_row);
+            for (size_t r0 = 0; r0 < rows; r0 += band) {
+                const size_t r1 = std::min(rows, r0 + band);
+                pack_rows(imgs, row_stride, frame_stride, e->h_in, dev_row, height, width_bytes, r0, r1);
+                HIP_TRY(e, hipMemcpyAsync(e->d_in + r0 * dev_row, e->h_in + r0 * dev_row, (r1 - r0) * dev_row, hipMemcpyHostToDevice, e->stream));
+            }
+        }
+    }
     uint8_t* h_cnt = hs.h_cnt, *h_kp = hs.h_kp, *h_desc = hs.h_desc;
     // One frame through a plan that exists: replay the captured graph, or capture it when this configuration
     // comes a second time (the first call of a configuration builds plan and buffers and runs the plain way).
@@ -1137,10 +1156,11 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
     bool replayed = false;
     if (graphable && !(e->graph_exec && same(key, e->graph_key)) && same(key, e->graph_seen)) {
         hipGraph_t graph = nullptr;
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));                 // (the images are up)
         if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
-        hipError_t st = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
-        if (st == hipSuccess) st = hipMemcpyAsync(e->d_in, e->h_in, need, hipMemcpyHostToDevice, e->stream);
+        // (relaxed mode: only launches and copies on this stream are issued between here and the end of the capture,
+        // and other threads - a second instance at work, src/Frame.cc:114-117 - go on making whatever calls they make)
+        hipError_t st = hipStreamBeginCapture(e->stream, hipStreamCaptureModeRelaxed);
         int prc = st == hipSuccess ? run_pass(e, e->ws[0], e->stream, e->d_in, 1, dev_row, dev_frame, dev_row, channels, rgb, e->d_out_kp,
                                               e->d_out_desc, e->d_out_cnt, cap, 0) : ORBHIP_ERR_HIP;
         if (prc == ORBHIP_OK) {
@@ -1179,7 +1199,6 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
     }
     e->graph_seen = key;
     if (!replayed) {
-        HIP_TRY(e, hipMemcpyAsync(e->d_in, e->h_in, need, hipMemcpyHostToDevice, e->stream));
         // (the staging buffer's rows are dev_row bytes long, all of them the library's own)
         rc = extract_device_impl(e, e->d_in, nframes, width, height, dev_row, dev_frame, dev_row, channels, rgb,
                                  reinterpret_cast<orbhip_keypoint*>(e->d_out_kp), e->d_out_desc, e->d_out_cnt, cap, nullptr);
