@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="frames (pairs with --stereo) per GPU per step in weak scaling")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch frames per GPU; strong: --total-batch frames over all GPUs (contiguous range per rank)")
-    ap.add_argument("--total-batch", type=int, default=1024, help="frames (pairs with --stereo) per step of the whole job in strong scaling")
+    ap.add_argument("--total-batch", type=int, default=None, help="frames (pairs with --stereo) per step of the whole job in strong scaling")
     ap.add_argument("--preset", default=None, choices=["c4_strong_1024", "c3_stereo_512"],
                     help="c4_strong_1024: 1024 1080p frames per step over all GPUs; c3_stereo_512: 512 EuRoC-shaped stereo pairs per step over all GPUs")
     ap.add_argument("--max-batch", type=int, default=0, help="frames per internal pass (0 = library default)")
@@ -160,9 +160,12 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses GPU 0 (use with --backend gloo)")
     args = ap.parse_args()
     if args.preset == "c4_strong_1024":
-        args.workload, args.scaling, args.total_batch, args.stereo = "C4_1080p_2000f", "strong", 1024, False
+        args.workload, args.scaling, args.stereo = "C4_1080p_2000f", "strong", False
+        args.total_batch = args.total_batch or 1024     # (--total-batch n: what one of 1024 / n ranks sees, on one GPU)
     elif args.preset == "c3_stereo_512":
-        args.workload, args.scaling, args.total_batch, args.stereo = "C3_euroc", "strong", 512, True
+        args.workload, args.scaling, args.stereo = "C3_euroc", "strong", True
+        args.total_batch = args.total_batch or 512
+    args.total_batch = args.total_batch or 1024
 
     import torch
     from visual_slam_amd import orbhip, synth
