@@ -15,11 +15,14 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define ITERS 8192
-#define NOPS 64
-static const char* const kOpNames[NOPS] = {"v_mov_b32", "v_add_u32", "v_sub_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshrrev_b32 const", "v_lshrrev_b32 vgpr", "v_lshlrev_b32 const", "v_min_i32", "v_max_u32", "v_min_u16", "v_max_i16", "v_sub_u16", "v_add_u16", "v_cndmask_b32", "v_mul_u32_u24", "v_mul_lo_u32", "v_mad_u32_u24", "v_add_f32", "v_mul_f32", "v_fma_f32", "v_add_u32 dpp row_shr:1", "v_mov_b32 dpp row_shr:1", "v_mov_b32 dpp wave_shr:1", "v_add_u32 sdwa WORD_1", "v_sub_u16 sdwa hi", "v_pk_min_i16", "v_pk_max_i16", "v_pk_sub_i16", "v_pk_add_u16", "v_pk_lshrrev_b16", "v_perm_b32", "v_and_or_b32", "v_or3_b32", "v_add3_u32", "v_lshl_or_b32", "v_lshl_add_u32", "v_bfe_u32", "v_bfi_b32", "v_alignbit_b32", "v_alignbyte_b32", "v_min3_i32", "v_med3_i32", "v_sad_u8", "v_sad_u16", "v_msad_u8", "v_dot4_u32_u8", "v_dot2_u32_u16", "v_bcnt_u32_b32", "v_mbcnt_lo_u32_b32", "v_cmp_gt_i32 (vcc)", "v_cvt_f32_i32", "v_rndne_f32", "v_ffbl_b32", "v_add_u32 (2 fresh srcs)", "v_sub_u32 (2 fresh srcs)", "v_or_b32 (2 fresh srcs)", "v_and_b32 (2 fresh srcs)", "v_add_u32 (src = sgpr)", "v_add_u32 (src = literal)", "v_lshrrev_b32 (fresh dst)", "v_mov_b32 (fresh)", "v_pk_min_i16 (2 fresh srcs)"};
+#define NOPS 71
+static const char* const kOpNames[NOPS] = {"v_mov_b32", "v_add_u32", "v_sub_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshrrev_b32 const", "v_lshrrev_b32 vgpr", "v_lshlrev_b32 const", "v_min_i32", "v_max_u32", "v_min_u16", "v_max_i16", "v_sub_u16", "v_add_u16", "v_cndmask_b32", "v_mul_u32_u24", "v_mul_lo_u32", "v_mad_u32_u24", "v_add_f32", "v_mul_f32", "v_fma_f32", "v_add_u32 dpp row_shr:1", "v_mov_b32 dpp row_shr:1", "v_mov_b32 dpp wave_shr:1", "v_add_u32 sdwa WORD_1", "v_sub_u16 sdwa hi", "v_pk_min_i16", "v_pk_max_i16", "v_pk_sub_i16", "v_pk_add_u16", "v_pk_lshrrev_b16", "v_perm_b32", "v_and_or_b32", "v_or3_b32", "v_add3_u32", "v_lshl_or_b32", "v_lshl_add_u32", "v_bfe_u32", "v_bfi_b32", "v_alignbit_b32", "v_alignbyte_b32", "v_min3_i32", "v_med3_i32", "v_sad_u8", "v_sad_u16", "v_msad_u8", "v_dot4_u32_u8", "v_dot2_u32_u16", "v_bcnt_u32_b32", "v_mbcnt_lo_u32_b32", "v_cmp_gt_i32 (vcc)", "v_cvt_f32_i32", "v_rndne_f32", "v_ffbl_b32", "v_add_u32 (2 fresh srcs)", "v_sub_u32 (2 fresh srcs)", "v_or_b32 (2 fresh srcs)", "v_and_b32 (2 fresh srcs)", "v_add_u32 (src = sgpr)", "v_add_u32 (src = literal)", "v_lshrrev_b32 (fresh dst)", "v_mov_b32 (fresh)", "v_pk_min_i16 (2 fresh srcs)",
+    "v_pk_minimum3_f16 (denormal operands)", "v_pk_maximum3_f16 (denormal operands)", "v_pk_min_f16 (denormal operands)", "v_pk_max_f16 (denormal operands)",
+    "v_min3_i16", "v_max3_u16", "v_pk_minimum3_f16 (normal operands)"};
 
 template <int OP>
 __device__ __forceinline__ void one(uint32_t& a, uint32_t b, uint32_t c, uint32_t d, uint32_t sg) {
@@ -33,6 +36,12 @@ __device__ __forceinline__ void one(uint32_t& a, uint32_t b, uint32_t c, uint32_
     else if (OP == 61) asm volatile("v_lshrrev_b32 %0, 1, %3" : "+v"(a) : "v"(b), "v"(c), "v"(d), "s"(sg) : "vcc");
     else if (OP == 62) asm volatile("v_mov_b32 %0, %3" : "+v"(a) : "v"(b), "v"(c), "v"(d), "s"(sg) : "vcc");
     else if (OP == 63) asm volatile("v_pk_min_i16 %0, %3, %1" : "+v"(a) : "v"(b), "v"(c), "v"(d), "s"(sg) : "vcc");
+    else if (OP == 64 || OP == 70) asm volatile("v_pk_minimum3_f16 %0, %0, %1, %3" : "+v"(a) : "v"(b), "v"(c), "v"(d), "s"(sg) : "vcc");
+    else if (OP == 65) asm volatile("v_pk_maximum3_f16 %0, %0, %1, %3" : "+v"(a) : "v"(b), "v"(c), "v"(d), "s"(sg) : "vcc");
+    else if (OP == 66) asm volatile("v_pk_min_f16 %0, %0, %1" : "+v"(a) : "v"(b), "v"(c), "v"(d), "s"(sg) : "vcc");
+    else if (OP == 67) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(a) : "v"(b), "v"(c), "v"(d), "s"(sg) : "vcc");
+    else if (OP == 68) asm volatile("v_min3_i16 %0, %0, %1, %3" : "+v"(a) : "v"(b), "v"(c), "v"(d), "s"(sg) : "vcc");
+    else if (OP == 69) asm volatile("v_max3_u16 %0, %0, %1, %3" : "+v"(a) : "v"(b), "v"(c), "v"(d), "s"(sg) : "vcc");
     else if (OP == 0) asm volatile("v_mov_b32 %0, %1" : "+v"(a) : "v"(b), "v"(c) : "vcc");
     else if (OP == 1) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(b), "v"(c) : "vcc");
     else if (OP == 2) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a) : "v"(b), "v"(c) : "vcc");
@@ -97,7 +106,11 @@ __global__ __launch_bounds__(256) void k_calib(uint64_t* __restrict__ delta, uin
     uint64_t t0, t1, r0, r1;
     uint32_t a[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) a[k] = b + k;
+    for (int k = 0; k < 16; k++) {
+        a[k] = b + k;
+        if (OP >= 64 && OP <= 69) a[k] = (a[k] * 0x00010001u) & 0x00FF00FFu;            // pixel values in 16-bit halves: denormal half floats
+        if (OP == 70) a[k] = ((a[k] * 0x00010001u) & 0x03FF03FFu) | 0x3C003C00u;      // half floats in [1, 2)
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) :: "memory");
     for (int i = 0; i < ITERS; i++) {
 #pragma unroll
@@ -144,76 +157,91 @@ static void run(int ncu, uint64_t* d_delta, uint32_t* d_sink) {
     }
 }
 
-int main() {
+static bool g_only[NOPS];
+static bool g_filter = false;
+template <int OP>
+static void run_if(int ncu, uint64_t* d_delta, uint32_t* d_sink) {
+    if (!g_filter || g_only[OP]) run<OP>(ncu, d_delta, d_sink);
+}
+
+int main(int argc, char** argv) {
+    for (int i = 1; i < argc; i++) { const int k = std::atoi(argv[i]); if (k >= 0 && k < NOPS) { g_only[k] = true; g_filter = true; } }   // run only the listed cases
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 1;
     const int ncu = prop.multiProcessorCount;
     std::printf("device %s, %d CUs, max clock %d MHz\n", prop.gcnArchName, ncu, prop.clockRate / 1000);
     uint64_t* d_delta = nullptr; uint32_t* d_sink = nullptr;
     if (hipMalloc(&d_delta, (size_t)ncu * 8 * 4 * 16) != hipSuccess || hipMalloc(&d_sink, 4) != hipSuccess) return 1;
-    run<0>(ncu, d_delta, d_sink);
-    run<1>(ncu, d_delta, d_sink);
-    run<2>(ncu, d_delta, d_sink);
-    run<3>(ncu, d_delta, d_sink);
-    run<4>(ncu, d_delta, d_sink);
-    run<5>(ncu, d_delta, d_sink);
-    run<6>(ncu, d_delta, d_sink);
-    run<7>(ncu, d_delta, d_sink);
-    run<8>(ncu, d_delta, d_sink);
-    run<9>(ncu, d_delta, d_sink);
-    run<10>(ncu, d_delta, d_sink);
-    run<11>(ncu, d_delta, d_sink);
-    run<12>(ncu, d_delta, d_sink);
-    run<13>(ncu, d_delta, d_sink);
-    run<14>(ncu, d_delta, d_sink);
-    run<15>(ncu, d_delta, d_sink);
-    run<16>(ncu, d_delta, d_sink);
-    run<17>(ncu, d_delta, d_sink);
-    run<18>(ncu, d_delta, d_sink);
-    run<19>(ncu, d_delta, d_sink);
-    run<20>(ncu, d_delta, d_sink);
-    run<21>(ncu, d_delta, d_sink);
-    run<22>(ncu, d_delta, d_sink);
-    run<23>(ncu, d_delta, d_sink);
-    run<24>(ncu, d_delta, d_sink);
-    run<25>(ncu, d_delta, d_sink);
-    run<26>(ncu, d_delta, d_sink);
-    run<27>(ncu, d_delta, d_sink);
-    run<28>(ncu, d_delta, d_sink);
-    run<29>(ncu, d_delta, d_sink);
-    run<30>(ncu, d_delta, d_sink);
-    run<31>(ncu, d_delta, d_sink);
-    run<32>(ncu, d_delta, d_sink);
-    run<33>(ncu, d_delta, d_sink);
-    run<34>(ncu, d_delta, d_sink);
-    run<35>(ncu, d_delta, d_sink);
-    run<36>(ncu, d_delta, d_sink);
-    run<37>(ncu, d_delta, d_sink);
-    run<38>(ncu, d_delta, d_sink);
-    run<39>(ncu, d_delta, d_sink);
-    run<40>(ncu, d_delta, d_sink);
-    run<41>(ncu, d_delta, d_sink);
-    run<42>(ncu, d_delta, d_sink);
-    run<43>(ncu, d_delta, d_sink);
-    run<44>(ncu, d_delta, d_sink);
-    run<45>(ncu, d_delta, d_sink);
-    run<46>(ncu, d_delta, d_sink);
-    run<47>(ncu, d_delta, d_sink);
-    run<48>(ncu, d_delta, d_sink);
-    run<49>(ncu, d_delta, d_sink);
-    run<50>(ncu, d_delta, d_sink);
-    run<51>(ncu, d_delta, d_sink);
-    run<52>(ncu, d_delta, d_sink);
-    run<53>(ncu, d_delta, d_sink);
-    run<54>(ncu, d_delta, d_sink);
-    run<55>(ncu, d_delta, d_sink);
-    run<56>(ncu, d_delta, d_sink);
-    run<57>(ncu, d_delta, d_sink);
-    run<58>(ncu, d_delta, d_sink);
-    run<59>(ncu, d_delta, d_sink);
-    run<60>(ncu, d_delta, d_sink);
-    run<61>(ncu, d_delta, d_sink);
-    run<62>(ncu, d_delta, d_sink);
-    run<63>(ncu, d_delta, d_sink);
+    run_if<0>(ncu, d_delta, d_sink);
+    run_if<1>(ncu, d_delta, d_sink);
+    run_if<2>(ncu, d_delta, d_sink);
+    run_if<3>(ncu, d_delta, d_sink);
+    run_if<4>(ncu, d_delta, d_sink);
+    run_if<5>(ncu, d_delta, d_sink);
+    run_if<6>(ncu, d_delta, d_sink);
+    run_if<7>(ncu, d_delta, d_sink);
+    run_if<8>(ncu, d_delta, d_sink);
+    run_if<9>(ncu, d_delta, d_sink);
+    run_if<10>(ncu, d_delta, d_sink);
+    run_if<11>(ncu, d_delta, d_sink);
+    run_if<12>(ncu, d_delta, d_sink);
+    run_if<13>(ncu, d_delta, d_sink);
+    run_if<14>(ncu, d_delta, d_sink);
+    run_if<15>(ncu, d_delta, d_sink);
+    run_if<16>(ncu, d_delta, d_sink);
+    run_if<17>(ncu, d_delta, d_sink);
+    run_if<18>(ncu, d_delta, d_sink);
+    run_if<19>(ncu, d_delta, d_sink);
+    run_if<20>(ncu, d_delta, d_sink);
+    run_if<21>(ncu, d_delta, d_sink);
+    run_if<22>(ncu, d_delta, d_sink);
+    run_if<23>(ncu, d_delta, d_sink);
+    run_if<24>(ncu, d_delta, d_sink);
+    run_if<25>(ncu, d_delta, d_sink);
+    run_if<26>(ncu, d_delta, d_sink);
+    run_if<27>(ncu, d_delta, d_sink);
+    run_if<28>(ncu, d_delta, d_sink);
+    run_if<29>(ncu, d_delta, d_sink);
+    run_if<30>(ncu, d_delta, d_sink);
+    run_if<31>(ncu, d_delta, d_sink);
+    run_if<32>(ncu, d_delta, d_sink);
+    run_if<33>(ncu, d_delta, d_sink);
+    run_if<34>(ncu, d_delta, d_sink);
+    run_if<35>(ncu, d_delta, d_sink);
+    run_if<36>(ncu, d_delta, d_sink);
+    run_if<37>(ncu, d_delta, d_sink);
+    run_if<38>(ncu, d_delta, d_sink);
+    run_if<39>(ncu, d_delta, d_sink);
+    run_if<40>(ncu, d_delta, d_sink);
+    run_if<41>(ncu, d_delta, d_sink);
+    run_if<42>(ncu, d_delta, d_sink);
+    run_if<43>(ncu, d_delta, d_sink);
+    run_if<44>(ncu, d_delta, d_sink);
+    run_if<45>(ncu, d_delta, d_sink);
+    run_if<46>(ncu, d_delta, d_sink);
+    run_if<47>(ncu, d_delta, d_sink);
+    run_if<48>(ncu, d_delta, d_sink);
+    run_if<49>(ncu, d_delta, d_sink);
+    run_if<50>(ncu, d_delta, d_sink);
+    run_if<51>(ncu, d_delta, d_sink);
+    run_if<52>(ncu, d_delta, d_sink);
+    run_if<53>(ncu, d_delta, d_sink);
+    run_if<54>(ncu, d_delta, d_sink);
+    run_if<55>(ncu, d_delta, d_sink);
+    run_if<56>(ncu, d_delta, d_sink);
+    run_if<57>(ncu, d_delta, d_sink);
+    run_if<58>(ncu, d_delta, d_sink);
+    run_if<59>(ncu, d_delta, d_sink);
+    run_if<60>(ncu, d_delta, d_sink);
+    run_if<61>(ncu, d_delta, d_sink);
+    run_if<62>(ncu, d_delta, d_sink);
+    run_if<63>(ncu, d_delta, d_sink);
+    run_if<64>(ncu, d_delta, d_sink);
+    run_if<65>(ncu, d_delta, d_sink);
+    run_if<66>(ncu, d_delta, d_sink);
+    run_if<67>(ncu, d_delta, d_sink);
+    run_if<68>(ncu, d_delta, d_sink);
+    run_if<69>(ncu, d_delta, d_sink);
+    run_if<70>(ncu, d_delta, d_sink);
     return 0;
 }

@@ -83,7 +83,26 @@ __device__ __forceinline__ int fast_score16(int v, const int (&p)[16]) {
     return max(v - amin, bmax - v) - 1;
 }
 
-// The same for two pixels at once: every value is a pair of 16-bit halves (packed min / max / sub).
+// Three-input packed minimum / maximum of pixel values. gfx950 has no three-input packed integer minimum, but
+// it has v_pk_minimum3_f16 / v_pk_maximum3_f16, and the values here are 0 .. 255 in 16-bit halves: read as half
+// floats those bit patterns are zero or positive denormals, whose order is the order of the integers, and the
+// result of a minimum or maximum is one of its inputs, bit for bit (kernels run with 16-bit denormals enabled,
+// the compiler's default; nothing here is NaN, infinite or negative).
+__device__ __forceinline__ v2s pmin3(v2s a, v2s b, v2s c) {
+    uint32_t d;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(v2u(a)), "v"(v2u(b)), "v"(v2u(c)));
+    return u2v(d);
+}
+__device__ __forceinline__ v2s pmax3(v2s a, v2s b, v2s c) {
+    uint32_t d;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(v2u(a)), "v"(v2u(b)), "v"(v2u(c)));
+    return u2v(d);
+}
+
+// The same for two pixels at once: every value is a pair of 16-bit halves (packed min / max / sub). The eight
+// ring pixels p[k+1..k+8] shared by the arcs [k..k+8] and [k+1..k+9] (k even) are the pairs (k+1,k+2) .. (k+7,k+8):
+// three of them reduce in one three-input instruction, the fourth joins the reduction with the pixel that tells the
+// two arcs apart (max(min(a, x), min(a, y)) = min(a, max(x, y))), and the eight results reduce three at a time.
 __device__ __forceinline__ v2s fast_score16_pk(v2s v, const v2s (&p)[16]) {
     v2s lo2[8], hi2[8];
 #pragma unroll
@@ -91,21 +110,17 @@ __device__ __forceinline__ v2s fast_score16_pk(v2s v, const v2s (&p)[16]) {
         lo2[j] = pmin(p[(2 * j + 1) & 15], p[(2 * j + 2) & 15]);
         hi2[j] = pmax(p[(2 * j + 1) & 15], p[(2 * j + 2) & 15]);
     }
-    v2s lo4[8], hi4[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        lo4[j] = pmin(lo2[j], lo2[(j + 1) & 7]);
-        hi4[j] = pmax(hi2[j], hi2[(j + 1) & 7]);
-    }
-    v2s amin = {512, 512}, bmax = {-512, -512};
+    v2s at[8], bt[8];   // per k = 2j: the brightest pixel of the darker-centre arc pair's best arc, and the mirror image
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int k = 2 * j;
-        const v2s lo8 = pmin(lo4[j], lo4[(j + 2) & 7]);
-        const v2s hi8 = pmax(hi4[j], hi4[(j + 2) & 7]);
-        amin = pmin(amin, pmax(hi8, pmin(p[k], p[(k + 9) & 15])));
-        bmax = pmax(bmax, pmin(lo8, pmax(p[k], p[(k + 9) & 15])));
+        const v2s lo6 = pmin3(lo2[j], lo2[(j + 1) & 7], lo2[(j + 2) & 7]);
+        const v2s hi6 = pmax3(hi2[j], hi2[(j + 1) & 7], hi2[(j + 2) & 7]);
+        at[j] = pmax3(hi6, hi2[(j + 3) & 7], pmin(p[k], p[(k + 9) & 15]));
+        bt[j] = pmin3(lo6, lo2[(j + 3) & 7], pmax(p[k], p[(k + 9) & 15]));
     }
+    const v2s amin = pmin(pmin3(pmin3(at[0], at[1], at[2]), pmin3(at[3], at[4], at[5]), at[6]), at[7]);
+    const v2s bmax = pmax(pmax3(pmax3(bt[0], bt[1], bt[2]), pmax3(bt[3], bt[4], bt[5]), bt[6]), bt[7]);
     const v2s one = {1, 1};
     return pmax(v - amin, bmax - v) - one;
 }
