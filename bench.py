@@ -291,12 +291,14 @@ def main():
             parts["k_stereo"] = 0
         kname = max(timing, key=lambda k: timing[k][0])
         k_ms, k_launches = timing[kname]
-        k_bytes_per_launch = parts[kname] * B * args.steps / max(k_launches, 1)
-        k_avg_s = k_ms * 1e-3 / max(k_launches, 1)
-        achieved = k_bytes_per_launch / k_avg_s / 1e9
         lanes = max(1, min(int(os.environ.get("ORBHIP_LANES", "1")), 4))
         passes = max(timing["k_quadtree"][1] // (2 if args.stereo else 1), 1)   # one quadtree launch per pass and side
         frames_per_launch = B * args.steps / passes
+        # A "launch" below is what a kernel class launches for one pass (k_fast: level 0 on the second stream, the other
+        # levels' plain tiles and the packed tiles; k_resize: the seven levels of the chain): bytes and time of a pass.
+        k_bytes_per_launch = parts[kname] * frames_per_launch
+        k_avg_s = k_ms * 1e-3 / passes
+        achieved = k_bytes_per_launch / k_avg_s / 1e9
         # the committed counter summaries were collected on the default workload: they say nothing about another one
         profiled = (args.workload == "C4_1080p_2000f" and args.kind == "blocks" and not args.stereo and not args.rectify
                     and not args.color)
@@ -305,6 +307,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": int(k_bytes_per_launch), "avg_launch_ms": round(k_avg_s * 1e3, 4),
+                    "launch_is": "the launches of the kernel class for one pass (%.1f timed spans per pass)" % (k_launches / passes),
                     "whole_path_bytes_per_frame": int(total_bytes),
                     "whole_path_frac": round(B * args.steps / dt * total_bytes / 1e9 / HBM_PEAK_GBS, 4),
                     "compulsory_bytes_per_frame": int(compulsory_bytes(w, h, scale, levels, nfeat)),
@@ -332,19 +335,31 @@ def main():
                                 "peak_insts_per_s": peak_arch, "cycles_per_inst_peak": 4.0, "frac": round(valu / k_avg_s / peak_arch, 4),
                                 "cycles_per_inst_calibrated": VALU_CYCLES_PER_INST, "calibration": "profiles/r02_valu_calib.txt",
                                 "frac_at_calibrated_4.25": round(valu / k_avg_s / peak_cal, 4)}
-        # with several passes in flight (ORBHIP_LANES > 1) also time the same kernels one at a time (a
-        # second handle limited to one pass, two untimed steps): a kernel with the GPU to itself
-        if lanes > 1:
-            lanes_env = os.environ.get("ORBHIP_LANES")
+        # By default level 0's FAST runs on a second stream beside the resize chain (ORBHIP_OVERLAP, passes of 32 frames
+        # and more), and ORBHIP_LANES > 1 keeps several passes in flight: the launch durations above are then those of
+        # kernels that share the chip. Also time the same kernels one at a time (a second handle with both switched
+        # off, two untimed steps): a kernel with the GPU to itself.
+        overlap_on = os.environ.get("ORBHIP_OVERLAP", "1") != "0" and not args.stereo
+        roofline["level0_fast_beside_resize"] = bool(overlap_on)
+        if lanes > 1 or overlap_on:
+            saved = {k: os.environ.get(k) for k in ("ORBHIP_LANES", "ORBHIP_OVERLAP")}
             os.environ["ORBHIP_LANES"] = "1"
+            os.environ["ORBHIP_OVERLAP"] = "0"
             ex1 = orbhip.ORBextractor(nfeat, scale, levels, ini_th, min_th, device=local_rank, max_batch=args.max_batch)
-            if lanes_env is None:
-                os.environ.pop("ORBHIP_LANES")
-            else:
-                os.environ["ORBHIP_LANES"] = lanes_env
+            if args.rectify:
+                ex1.set_rectification(*synth.rectify_maps(w, h))
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k)
+                else:
+                    os.environ[k] = v
             def step1():
-                ex1.extract_batch_device(frames.data_ptr(), B, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(),
-                                         d_cnt.data_ptr(), cap, stream.cuda_stream)
+                if args.color:
+                    ex1.extract_batch_device_color(frames_c.data_ptr(), B, w, h, w * args.color, w * h * args.color, args.color, 0,
+                                                   d_kp.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(), cap, stream.cuda_stream)
+                else:
+                    ex1.extract_batch_device(frames.data_ptr(), B, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(),
+                                             d_cnt.data_ptr(), cap, stream.cuda_stream)
             step1()
             torch.cuda.synchronize()
             ex1.enable_timing(True)
@@ -353,11 +368,13 @@ def main():
             t1 = ex1.timing()
             ex1.enable_timing(False)
             s_ms, s_launches = t1[kname]
-            s_bytes = parts[kname] * B * 2 / max(s_launches, 1)
-            s_avg = s_ms * 1e-3 / max(s_launches, 1)
-            roofline["one_pass_in_flight"] = {"achieved": round(s_bytes / s_avg / 1e9, 1), "frac": round(s_bytes / s_avg / 1e9 / HBM_PEAK_GBS, 4),
-                                              "bytes_per_launch": int(s_bytes), "avg_launch_ms": round(s_avg * 1e3, 4),
-                                              "kernel_ms_per_step": {k: round(v[0] / 2, 3) for k, v in t1.items()}}
+            s_passes = max(t1["k_quadtree"][1], 1)
+            s_bytes = parts[kname] * B * 2 / s_passes
+            s_avg = s_ms * 1e-3 / s_passes
+            roofline["kernels_one_at_a_time"] = {"achieved": round(s_bytes / s_avg / 1e9, 1), "frac": round(s_bytes / s_avg / 1e9 / HBM_PEAK_GBS, 4),
+                                                 "bytes_per_launch": int(s_bytes), "avg_launch_ms": round(s_avg * 1e3, 4),
+                                                 "kernel_ms_per_step": {k: round(v[0] / 2, 3) for k, v in t1.items()},
+                                                 "ms_per_step": round(sum(v[0] for v in t1.values()) / 2, 3)}
             del ex1
         cpu = None
         if args.cpu_frames < 0:

@@ -56,9 +56,9 @@ def test_two_instances_on_two_threads_like_stereo():
 
 @pytest.mark.gpu
 def test_two_passes_in_flight_give_the_same_results():
-    """ORBHIP_LANES=2 splits a large batch into passes on two internal streams, ORBHIP_OVERLAP=1 runs
-    level 0's FAST beside the resize chain on a second stream (both read at handle creation, so they
-    run in child processes); the outputs must equal the single-stream ones."""
+    """ORBHIP_LANES=2 splits a large batch into passes on two internal streams, ORBHIP_OVERLAP=1 (the default
+    for passes of 32 frames and more) runs level 0's FAST beside the resize chain on a second stream (both read
+    at handle creation, so they run in child processes); the outputs must equal the single-stream ones."""
     import os
     import subprocess
     import sys
@@ -79,7 +79,8 @@ def test_two_passes_in_flight_give_the_same_results():
     with tempfile.TemporaryDirectory() as tmp:
         for lanes, overlap in (("1", "0"), ("2", "0"), ("1", "1"), ("2", "1")):
             path = os.path.join(tmp, "lanes%s_%s.npz" % (lanes, overlap))
-            env = dict(os.environ, ORBHIP_LANES=lanes, ORBHIP_OVERLAP=overlap)
+            # (the host batch call in one piece, so that it runs as passes of 64 and 16 frames through the device entry point)
+            env = dict(os.environ, ORBHIP_LANES=lanes, ORBHIP_OVERLAP=overlap, ORBHIP_HOST_PIPELINE="0")
             subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=240)
             with np.load(path) as z:
                 out[lanes + overlap] = {k: z[k] for k in z.files}

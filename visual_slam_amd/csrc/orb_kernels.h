@@ -323,8 +323,10 @@ __global__ __launch_bounds__(256) void k_level0_remap(const uint8_t* __restrict_
 // source rows of the RS_RPT output rows of a wave are requested before any arithmetic starts.
 // ------------------------------------------------------------------------------------------------
 #ifndef RS_RPT
-#define RS_RPT 10   // rows per lane: 8 / 10 / 12 / 16 rows measure 1.47 / 1.41 / 1.41 / 1.45 ms per 512 1080p frames (fewer
-                    // source rows read twice against fewer waves per SIMD: 72 / 88 / 104 / 136 registers)
+#define RS_RPT 8    // rows per lane: 8 / 10 / 12 / 16 rows measure 1.47 / 1.41 / 1.41 / 1.45 ms per 512 1080p frames when the chain
+                    // runs alone (fewer source rows read twice against fewer waves per SIMD: 72 / 88 / 104 / 136 registers);
+                    // with 72 registers a wave of this kernel fits a SIMD beside the FAST waves of level 0, which run on a
+                    // second stream while the chain works: the two together take 0.2 ms less than one after the other
 #endif
 
 typedef unsigned short v2us __attribute__((ext_vector_type(2)));

@@ -68,6 +68,7 @@ const int kLanes = 4;
 // against 0.336, 1080p / 2000 1.13 against 0.82
 const int kQtSmallQuota = 300;
 const int kQtLatencyGroups = 256;   // (frames x levels) up to this: a pass that cannot fill the chip
+const int kOverlapMinFrames = 32;  // passes from this size on run level 0's FAST on a second stream beside the resize chain
 const int kMinLaneFrames = 16;     // batches below twice this run as one pass on the caller's stream
 const int kPipelineMinFrames = 8;  // host batches from this size on are cut into chunks that overlap copy, extraction and copy back
 
@@ -130,7 +131,7 @@ struct orbhip_extractor {
     int fast_pack = 1;             // ORBHIP_FAST_PACK=0: every tile of k_fast is a plain one (no bands in the last tile column)
     int inplace_l0 = 1;            // ORBHIP_INPLACE_LEVEL0=0: always copy gray input into the level-0 plane
     std::vector<int> l1_base;      // per 4-pixel group of level 1's plane: 4-aligned first source column of its taps
-    int overlap = 0;               // ORBHIP_OVERLAP=1: FAST of level 0 runs beside the resize chain on aux_stream
+    int overlap = 1;               // ORBHIP_OVERLAP=0: FAST of level 0 does not run beside the resize chain on aux_stream
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_l0 = nullptr, ev_f0 = nullptr;
     hipEvent_t ev_busy = nullptr;    // end of the last extraction call: a call on another stream waits for it
@@ -583,7 +584,7 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
     if (int rc = debug_sync_point(e, s, "level 0")) return rc;
     // FAST is bound by vector issue, the resize chain by memory: with `overlap` level 0's FAST runs on
     // a second stream beside the chain and the remaining levels follow on the main stream
-    const unsigned split = (e->overlap && nl > 1) ? P.fast_cum[0][1] * (unsigned)frames : 0u;
+    const unsigned split = (e->overlap && nl > 1 && frames >= kOverlapMinFrames) ? P.fast_cum[0][1] * (unsigned)frames : 0u;
     if (split) {
         HIP_TRY(e, hipEventRecord(e->ev_l0, s));
         HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->ev_l0, 0));
@@ -1150,7 +1151,7 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
     auto same = [](const orbhip_extractor::GraphKey& a, const orbhip_extractor::GraphKey& b) {
         return a.w == b.w && a.h == b.h && a.channels == b.channels && a.rgb == b.rgb && a.cap == b.cap && a.gen == b.gen;
     };
-    const bool graphable = e->use_graph && nframes == 1 && !e->timing && !e->overlap && e->plan_w == width && e->plan_h == height &&
+    const bool graphable = e->use_graph && nframes == 1 && !e->timing && e->plan_w == width && e->plan_h == height &&
                            e->plan_frames >= 1 && e->plan_lanes >= 1 &&
                            !(e->d_map_x && (channels != 1 || width != e->map_w || height != e->map_h || width < 2 || height < 2));
     bool replayed = false;
