@@ -339,7 +339,8 @@ def main():
         # and more), and ORBHIP_LANES > 1 keeps several passes in flight: the launch durations above are then those of
         # kernels that share the chip. Also time the same kernels one at a time (a second handle with both switched
         # off, two untimed steps): a kernel with the GPU to itself.
-        overlap_on = os.environ.get("ORBHIP_OVERLAP", "1") != "0" and not args.stereo
+        ov = os.environ.get("ORBHIP_OVERLAP", "1")
+        overlap_on = not args.stereo and (ov == "2" or (ov != "0" and frames_per_launch * w * h >= 2.0e8))   # the library's own rule
         roofline["level0_fast_beside_resize"] = bool(overlap_on)
         if lanes > 1 or overlap_on:
             saved = {k: os.environ.get(k) for k in ("ORBHIP_LANES", "ORBHIP_OVERLAP")}

@@ -68,7 +68,7 @@ const int kLanes = 4;
 // against 0.336, 1080p / 2000 1.13 against 0.82
 const int kQtSmallQuota = 300;
 const int kQtLatencyGroups = 256;   // (frames x levels) up to this: a pass that cannot fill the chip
-const int kOverlapMinFrames = 32;  // passes from this size on run level 0's FAST on a second stream beside the resize chain
+const double kOverlapMinPixels = 2.0e8;   // passes of at least this many input pixels run level 0's FAST on a second stream beside the resize chain
 const int kMinLaneFrames = 16;     // batches below twice this run as one pass on the caller's stream
 const int kPipelineMinFrames = 8;  // host batches from this size on are cut into chunks that overlap copy, extraction and copy back
 
@@ -131,7 +131,7 @@ struct orbhip_extractor {
     int fast_pack = 1;             // ORBHIP_FAST_PACK=0: every tile of k_fast is a plain one (no bands in the last tile column)
     int inplace_l0 = 1;            // ORBHIP_INPLACE_LEVEL0=0: always copy gray input into the level-0 plane
     std::vector<int> l1_base;      // per 4-pixel group of level 1's plane: 4-aligned first source column of its taps
-    int overlap = 1;               // ORBHIP_OVERLAP=0: FAST of level 0 does not run beside the resize chain on aux_stream
+    int overlap = 1;               // ORBHIP_OVERLAP=0: FAST of level 0 never runs beside the resize chain on aux_stream; 2: for passes of any size
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_l0 = nullptr, ev_f0 = nullptr;
     hipEvent_t ev_busy = nullptr;    // end of the last extraction call: a call on another stream waits for it
@@ -584,7 +584,10 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
     if (int rc = debug_sync_point(e, s, "level 0")) return rc;
     // FAST is bound by vector issue, the resize chain by memory: with `overlap` level 0's FAST runs on
     // a second stream beside the chain and the remaining levels follow on the main stream
-    const unsigned split = (e->overlap && nl > 1 && frames >= kOverlapMinFrames) ? P.fast_cum[0][1] * (unsigned)frames : 0u;
+    // (measured per pass: 1080p x 128 frames +1.7 %, x 1024 +2.8 %, 4K x 128 +1.7 %, 1241 x 376 x 1024 +1.5 %, VGA x 1024 +0.4 %;
+    // 1080p x 64 -1 %, 752 x 480 x 512 -1.1 %, VGA x 64 -5 %: the fork and join cost more than a short chain can hide)
+    const bool beside = e->overlap && nl > 1 && (e->overlap > 1 || (double)frames * P.lv[0].w * P.lv[0].h >= kOverlapMinPixels);
+    const unsigned split = beside ? P.fast_cum[0][1] * (unsigned)frames : 0u;
     if (split) {
         HIP_TRY(e, hipEventRecord(e->ev_l0, s));
         HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->ev_l0, 0));
@@ -768,7 +771,7 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
     if (const char* v = std::getenv("ORBHIP_QT_THREADS")) { const int t = std::atoi(v); e->qt_threads = (t == 128 || t == 256) ? t : 0; }
     if (const char* v = std::getenv("ORBHIP_DEBUG_SYNC")) e->debug_sync = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_LANES")) e->max_lanes = std::min(kLanes, std::max(1, std::atoi(v)));
-    if (const char* v = std::getenv("ORBHIP_OVERLAP")) e->overlap = std::atoi(v) != 0;
+    if (const char* v = std::getenv("ORBHIP_OVERLAP")) e->overlap = std::min(2, std::max(0, std::atoi(v)));
     if (const char* v = std::getenv("ORBHIP_INPLACE_LEVEL0")) e->inplace_l0 = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_FAST_PACK")) e->fast_pack = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_GRAPH")) e->use_graph = std::atoi(v) != 0;
@@ -1151,7 +1154,7 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
     auto same = [](const orbhip_extractor::GraphKey& a, const orbhip_extractor::GraphKey& b) {
         return a.w == b.w && a.h == b.h && a.channels == b.channels && a.rgb == b.rgb && a.cap == b.cap && a.gen == b.gen;
     };
-    const bool graphable = e->use_graph && nframes == 1 && !e->timing && e->plan_w == width && e->plan_h == height &&
+    const bool graphable = e->use_graph && nframes == 1 && !e->timing && e->overlap < 2 && e->plan_w == width && e->plan_h == height &&
                            e->plan_frames >= 1 && e->plan_lanes >= 1 &&
                            !(e->d_map_x && (channels != 1 || width != e->map_w || height != e->map_h || width < 2 || height < 2));
     bool replayed = false;
