@@ -116,6 +116,23 @@ static inline unsigned grid_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)(
 #ifdef __HIPCC__
 // Unsigned 24-bit multiply (low 32 bits of the product). HIP declares __umul24 with an int result: a product
 // of 2^31 or more would then be shifted arithmetically (the cell divisions below shift by 22).
+//
+// Contract of every 24-bit multiply in the kernels (umul24 / __mul24 read only the low 24 bits of their
+// operands and return the low 32 bits of the product), with the bound that keeps each site inside it.
+// The host refuses images beyond 16384 pixels a side and checks the size-dependent bounds in ensure_plan:
+//   cell division   umul24(n, ceil(2^22 / d)) >> 22 == n / d   n < 16384 (a level coordinate), d = wcell or hcell >= 30,
+//                   so the factor is below 2^18, the product below 2^32, and the quotient exact while n * d < 2^22
+//                   (checked per level on the host); the remainder n - __mul24(q, d): q < 547, d < 16384
+//   cell index      __mul24(cy, ncols): cy, ncols < 547
+//   key order       umul24(cell, hcell) and umul24(cell * hcell + yin, wcell) in k_quadtree: cell * hcell + yin is below
+//                   rows-of-the-level * ncols < 2^24 (checked per level on the host), the second product below w * h <= 2^28
+//   LDS offsets     __mul24(row, FT_P): row < 48, FT_P = 260; __mul24(band, FT_ROWS), __mul24(band, 4 * lpb): band < 32;
+//                   __mul24(irx, DS_HP_P) in k_describe: the low 24 bits of irx are 0x400000 + rx with |rx| <= 19 (see there)
+//   band division   umul24(lane, ceil(2^16 / lpb)) >> 16: lane < 64, factor <= 2^16 / 3
+//   resize          umul24(weight, row value): an 11-bit weight times a 15-bit value
+//   moments         __mul24(15, s0), __mul24(lane - 15, s0): s0 <= 31 * 255
+//   stereo windows  __mul24(y, pitch): y < 16384 + 38, pitch <= 16384 + 128, product below the plane size < 2^31 (checked on
+//                   the host); __mul24(t, 745) >> 13 == t / 11 for t < 121
 __device__ __forceinline__ uint32_t umul24(uint32_t a, uint32_t b) { return (uint32_t)__umul24(a, b); }
 
 // Workgroups are dealt to the 8 XCDs (each with its own L2) round-robin in dispatch order, so

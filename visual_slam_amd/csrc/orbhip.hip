@@ -367,7 +367,11 @@ int ensure_plan(orbhip_extractor* e, int w, int h, int frames, int lanes) {
             g.hcell_magic = (unsigned)((1ull << 32) / (unsigned)g.hcell + 1);
             g.wcell_m22 = ((1u << 22) + g.wcell - 1) / g.wcell;
             g.hcell_m22 = ((1u << 22) + g.hcell - 1) / g.hcell;
-            if ((long long)g.w * g.wcell >= (1 << 22) || (long long)g.h * g.hcell >= (1 << 22)) { e->err = "image too large for the cell arithmetic"; return ORBHIP_ERR_GEOMETRY; }
+            // operand bounds of the kernels' 24-bit multiplies that depend on the image size (listed at umul24 in orb_device.h)
+            if ((long long)g.w * g.wcell >= (1 << 22) || (long long)g.h * g.hcell >= (1 << 22) ||
+                (long long)g.h * g.ncols >= (1 << 24) || g.plane_bytes >= (1ull << 31)) {
+                e->err = "image too large for the cell arithmetic"; return ORBHIP_ERR_GEOMETRY;
+            }
             g.n_ini = (int)std::round(width / (float)(g.maxby - ORB_MINB));   // src/ORBextractor.cc:543
             if (g.n_ini < 1) { e->err = "image too narrow for the quadtree (nIni == 0)"; return ORBHIP_ERR_GEOMETRY; }
             g.hx = width / (float)g.n_ini;                                  // src/ORBextractor.cc:545
