@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--host-fed", action="store_true", help="also time the PCIe-inclusive host-buffer entry point")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for the barrier / max-time reduction")
     ap.add_argument("--fast-th", default=None, help="INI,MIN: other FAST thresholds than the workload's (an experiment, named in config.fast_th)")
+    ap.add_argument("--skip-alone", action="store_true", help="do not time the kernels one at a time after the timed steps (profile runs)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses GPU 0 (use with --backend gloo)")
     args = ap.parse_args()
     if args.preset == "c4_strong_1024":
@@ -340,9 +341,9 @@ def main():
         # kernels that share the chip. Also time the same kernels one at a time (a second handle with both switched
         # off, two untimed steps): a kernel with the GPU to itself.
         ov = os.environ.get("ORBHIP_OVERLAP", "1")
-        overlap_on = not args.stereo and (ov == "2" or (ov != "0" and frames_per_launch * w * h >= 2.0e8))   # the library's own rule
+        overlap_on = not args.stereo and (ov == "2" or (ov != "0" and w * h >= 4.0e5 and frames_per_launch * w * h >= 2.0e8))   # the library's own rule
         roofline["level0_fast_beside_resize"] = bool(overlap_on)
-        if lanes > 1 or overlap_on:
+        if (lanes > 1 or overlap_on) and not args.skip_alone:
             saved = {k: os.environ.get(k) for k in ("ORBHIP_LANES", "ORBHIP_OVERLAP")}
             os.environ["ORBHIP_LANES"] = "1"
             os.environ["ORBHIP_OVERLAP"] = "0"

@@ -10,7 +10,7 @@ Reads <prefix>_{lds,issue,clk,fetch,write}.txt (per-kernel counter sums, tools/p
 <prefix>_trace.txt (kernel durations, tools/prof_summary.py) and prints, per kernel and PASS (one pass =
 one batch of frames through the pipeline = one launch of k_describe / k_stereo_match / the matcher; the
 template variants of a kernel and its launches per pass -- seven k_resize, two k_fast -- are added up):
-  time            duration per pass (kernel trace)
+  time            duration per pass (kernel trace; <prefix>_trace_alone.txt, kernels one at a time, where it exists)
   clock           GRBM_GUI_ACTIVE / 8 XCDs / duration
   valu_busy       SQ_ACTIVE_INST_VALU (quad-cycles) * 4 / (1024 SIMDs * cycles)
   lds_busy        SQ_LDS_IDX_ACTIVE / (256 CUs * cycles)
@@ -60,7 +60,9 @@ def per_pass(pair):
 
 def durations():
     calls, total = defaultdict(int), defaultdict(float)
-    f = d / ("%s_trace.txt" % prefix)
+    f = d / ("%s_trace_alone.txt" % prefix)                   # one kernel at a time, as the counter passes run them
+    if not f.exists():
+        f = d / ("%s_trace.txt" % prefix)
     if not f.exists():
         return {}
     for line in f.read_text().splitlines():

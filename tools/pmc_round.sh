@@ -22,8 +22,11 @@ trace() {   # name, program...: kernel durations (rocprofv3 --kernel-trace --sta
     python3 tools/prof_summary.py "$db" > $out/$name.txt 2>&1 && rm -f "$db" $out/$name.log
     find $out -name "${name}_*.csv" -delete
 }
-B="python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --batch 512"
-trace ext_trace python3 bench.py --cpu-frames 0 --batch 512 && run ext_lds "$LDS" $B && run ext_issue "$ISSUE" $B && run ext_fetch FETCH_SIZE $B && run ext_write WRITE_SIZE $B && run ext_clk GRBM_GUI_ACTIVE $B || exit 1
+B="python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --batch 512 --skip-alone"
+# kernel durations twice: as the bench runs them (level 0's FAST beside the resize chain: each of the two takes longer
+# than alone, the pair less than one after the other) and one kernel at a time (ORBHIP_OVERLAP=0), which is also how
+# the counter passes see them (the profiler serialises kernels while it collects counters)
+trace ext_trace python3 bench.py --cpu-frames 0 --batch 512 --skip-alone && ORBHIP_OVERLAP=0 trace ext_trace_alone python3 bench.py --cpu-frames 0 --batch 512 --skip-alone && run ext_lds "$LDS" $B && run ext_issue "$ISSUE" $B && run ext_fetch FETCH_SIZE $B && run ext_write WRITE_SIZE $B && run ext_clk GRBM_GUI_ACTIVE $B || exit 1
 if [ "$2" != "ext" ]; then
     S="python3 bench.py --stereo --workload C2_kitti --steps 2 --warmup 1 --cpu-frames 0 --batch 256"
     trace st_trace $S && run st_lds "$LDS" $S && run st_issue "$ISSUE" $S && run st_fetch FETCH_SIZE $S && run st_write WRITE_SIZE $S && run st_clk GRBM_GUI_ACTIVE $S || exit 1

@@ -68,7 +68,8 @@ const int kLanes = 4;
 // against 0.336, 1080p / 2000 1.13 against 0.82
 const int kQtSmallQuota = 300;
 const int kQtLatencyGroups = 256;   // (frames x levels) up to this: a pass that cannot fill the chip
-const double kOverlapMinPixels = 2.0e8;   // passes of at least this many input pixels run level 0's FAST on a second stream beside the resize chain
+const double kOverlapMinPixels = 2.0e8;   // passes of at least this many input pixels, of images of at least kOverlapMinImage pixels,
+const double kOverlapMinImage = 4.0e5;    // run level 0's FAST on a second stream beside the resize chain
 const int kMinLaneFrames = 16;     // batches below twice this run as one pass on the caller's stream
 const int kPipelineMinFrames = 8;  // host batches from this size on are cut into chunks that overlap copy, extraction and copy back
 
@@ -589,8 +590,10 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
     // FAST is bound by vector issue, the resize chain by memory: with `overlap` level 0's FAST runs on
     // a second stream beside the chain and the remaining levels follow on the main stream
     // (measured per pass: 1080p x 128 frames +1.7 %, x 1024 +2.8 %, 4K x 128 +1.7 %, 1241 x 376 x 1024 +1.5 %, VGA x 1024 +0.4 %;
-    // 1080p x 64 -1 %, 752 x 480 x 512 -1.1 %, VGA x 64 -5 %: the fork and join cost more than a short chain can hide)
-    const bool beside = e->overlap && nl > 1 && (e->overlap > 1 || (double)frames * P.lv[0].w * P.lv[0].h >= kOverlapMinPixels);
+    // 1080p x 64 -1 %, 752 x 480 x 512 -1.1 %, VGA x 64 -5 %: the fork and join cost more than a short chain can hide;
+    // VGA-class images lose a little at any batch size: their seven resize launches are too short to sit beside anything)
+    const double px0 = (double)P.lv[0].w * P.lv[0].h;
+    const bool beside = e->overlap && nl > 1 && (e->overlap > 1 || (px0 >= kOverlapMinImage && (double)frames * px0 >= kOverlapMinPixels));
     const unsigned split = beside ? P.fast_cum[0][1] * (unsigned)frames : 0u;
     if (split) {
         HIP_TRY(e, hipEventRecord(e->ev_l0, s));
