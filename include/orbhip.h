@@ -97,10 +97,11 @@ int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int 
 
 /* Host-buffer variant of the batch call: what Frame::ExtractORB (src/Frame.cc:272-278) does per image, for
  * `nframes` images in host memory; waits for the results. Batches of 8 frames and more run as a pipeline of
- * chunks (about 64 MB of images each, ORBHIP_HOST_CHUNK=n frames overrides) over three internal streams and
- * workspaces: while one chunk is packed into page-locked memory by a few host threads (ORBHIP_PACK_THREADS,
+ * chunks (about 64 MB of images each, ORBHIP_HOST_CHUNK=n frames overrides) over three internal streams, one
+ * per stage: while one chunk is packed into page-locked memory by a few host threads (ORBHIP_PACK_THREADS,
  * default half of the CPUs the process may use, at most 4), the previous one travels to the device, the one
- * before is extracted and the results of the one before that travel back. Images that already lie in
+ * before is extracted and the results of the one before that travel back (ORBHIP_HOST_LANES=2..4 chunks in
+ * flight, default 3; ORBHIP_HOST_TRACE=1 prints the timeline of a call on stderr). Images that already lie in
  * page-locked memory (hipHostMalloc / hipHostRegister) are copied from where they are, without the packing
  * step. ORBHIP_HOST_PIPELINE=0 (read by orbhip_create) restores one copy up, all passes, one copy down.
  * After the call orbhip_pyramid_copy sees the frames of the last chunk only. */

@@ -53,7 +53,7 @@ def _same(res, ref):
 
 
 def test_pipelined_host_batch_spans_many_chunks():
-    """41 frames in chunks of 5: nine chunks over three workspaces, the last one short."""
+    """41 frames in chunks of 5: nine chunks over three input buffers, the last one short."""
     from visual_slam_amd import orbhip
     imgs = _frames(41)
     ref = _singles(orbhip, imgs)

@@ -8,6 +8,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -106,6 +107,13 @@ hipError_t noalloc_scratch_ptr(int device, void** out) {
 }
 } // namespace
 
+static int default_pack_threads() {
+    int c = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) c = CPU_COUNT(&set);
+    return std::max(1, std::min(c / 2, 4));
+}
+
 struct orbhip_extractor {
     orbhip_params prm;
     double scale_factor_d;
@@ -135,6 +143,7 @@ struct orbhip_extractor {
     int overlap = 1;               // ORBHIP_OVERLAP=0: FAST of level 0 never runs beside the resize chain on aux_stream; 2: for passes of any size
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_l0 = nullptr, ev_f0 = nullptr;
+    hipEvent_t ev_up[kLanes] = {}, ev_run[kLanes] = {}, ev_down[kLanes] = {};   // per input buffer of the pipelined host batch call: copied up, extracted, results down
     hipEvent_t ev_busy = nullptr;    // end of the last extraction call: a call on another stream waits for it
     hipEvent_t ev_order = nullptr;   // orders work of another instance (stereo matching) against this one's stream
     hipStream_t last_stream = nullptr;   // stream of the last batch call
@@ -158,7 +167,9 @@ struct orbhip_extractor {
     // invalidates the captured pointers: a new plan, new staging buffers, new rectification maps.
     int use_graph = 1;
     int host_pipeline = 1;         // ORBHIP_HOST_PIPELINE=0: the host batch call runs as one copy up, all passes, one copy down
-    int host_lanes = 3;            // ORBHIP_HOST_LANES=2..4: chunks of the pipelined host batch call in flight
+    bool host_trace = false;       // ORBHIP_HOST_TRACE=1: the pipelined host batch call prints its timeline on stderr
+    int host_lanes = 3;            // ORBHIP_HOST_LANES=2..4: chunks of the pipelined host batch call in flight (input buffers)
+    int pack_threads = 1;          // ORBHIP_PACK_THREADS=n: host threads that pack pageable images into page-locked staging (default: half the CPUs the process may use, at most 4)
     int host_chunk = 0;            // ORBHIP_HOST_CHUNK=n: frames per chunk of the pipelined host batch call (0: about 64 MB of images)
     hipGraphExec_t graph_exec = nullptr;
     struct GraphKey { int w, h, channels, rgb, cap; unsigned long long gen; } graph_key = {0, 0, 0, 0, 0, 0}, graph_seen = {0, 0, 0, 0, 0, 0};
@@ -773,6 +784,10 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
     for (Workspace& w : e->ws)
         ok = ok && hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&w.done, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < kLanes; k++)
+        ok = ok && hipEventCreateWithFlags(&e->ev_up[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&e->ev_run[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&e->ev_down[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) { orbhip_destroy(e); return ORBHIP_ERR_HIP; }
     if (const char* v = std::getenv("ORBHIP_DEBUG_SKIP_DESCRIBE")) e->debug_skip_describe = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_QT_THREADS")) { const int t = std::atoi(v); e->qt_threads = (t == 128 || t == 256) ? t : 0; }
@@ -784,6 +799,9 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
     if (const char* v = std::getenv("ORBHIP_GRAPH")) e->use_graph = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_HOST_PIPELINE")) e->host_pipeline = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_HOST_CHUNK")) e->host_chunk = std::max(0, std::atoi(v));
+    e->pack_threads = default_pack_threads();
+    if (const char* v = std::getenv("ORBHIP_PACK_THREADS")) e->pack_threads = std::min(32, std::max(1, std::atoi(v)));
+    if (const char* v = std::getenv("ORBHIP_HOST_TRACE")) e->host_trace = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_HOST_LANES")) e->host_lanes = std::min(kLanes, std::max(2, std::atoi(v)));
     if (const char* v = std::getenv("ORBHIP_QT_LDS_LIMIT")) e->qt_lds_limit = std::min<size_t>(160 * 1024 - 256, (size_t)std::max(std::atoi(v), 1024));
     *out = e;
@@ -810,6 +828,9 @@ int orbhip_destroy(orbhip_extractor* e) {
         if (w.stream) (void)hipStreamDestroy(w.stream);
         if (w.done) (void)hipEventDestroy(w.done);
     }
+    for (int k = 0; k < kLanes; k++)
+        for (hipEvent_t ev : {e->ev_up[k], e->ev_run[k], e->ev_down[k]})
+            if (ev) (void)hipEventDestroy(ev);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_l0) (void)hipEventDestroy(e->ev_l0);
     if (e->ev_f0) (void)hipEventDestroy(e->ev_f0);
@@ -912,17 +933,6 @@ int orbhip_synchronize(orbhip_extractor* e) {
 // Worker threads for packing a chunk of caller images into pinned memory: half of the CPUs this process may
 // run on, at most 4 (ORBHIP_PACK_THREADS overrides; a GPU box reports the whole machine in
 // hardware_concurrency, the affinity mask is what the process really has).
-static int pack_threads() {
-    static const int n = [] {
-        if (const char* v = std::getenv("ORBHIP_PACK_THREADS")) return std::min(32, std::max(1, std::atoi(v)));
-        int c = 1;
-        cpu_set_t set;
-        if (sched_getaffinity(0, sizeof set, &set) == 0) c = CPU_COUNT(&set);
-        return std::max(1, std::min(c / 2, 4));
-    }();
-    return n;
-}
-
 // Rows [r0, r1) of the `n` frames starting at `src` (rows counted through all frames) into the staging layout
 // (rows of dev_row bytes, frames of height rows). The caller owns width_bytes of every source row, not the
 // padding behind it.
@@ -940,10 +950,10 @@ static void pack_rows(const uint8_t* src, size_t row_stride, size_t frame_stride
 }
 
 static void pack_frames(const uint8_t* src, size_t row_stride, size_t frame_stride, uint8_t* dst, size_t dev_row, int height,
-                        size_t width_bytes, int n) {
+                        size_t width_bytes, int n, int threads) {
     const size_t rows = (size_t)n * (size_t)height;
     const size_t bytes = rows * width_bytes;
-    const int nt = (int)std::min<size_t>((size_t)pack_threads(), std::max<size_t>(1, bytes >> 22));   // a thread per 4 MB at least
+    const int nt = (int)std::min<size_t>((size_t)threads, std::max<size_t>(1, bytes >> 22));   // a thread per 4 MB at least
     if (nt <= 1) { pack_rows(src, row_stride, frame_stride, dst, dev_row, height, width_bytes, 0, rows); return; }
     std::vector<std::thread> th;
     th.reserve((size_t)nt - 1);
@@ -1035,11 +1045,14 @@ static void unpack_frames(const HostStage& hs, int f0, int n, int cap, orbhip_ke
     }
 }
 
-// A batch of host images as a pipeline of chunks over up to three workspaces and streams: while chunk k's images are
-// packed into pinned memory by a few host threads (or read straight from the caller's buffer when that is page-locked),
-// chunk k-1 is on its way up, chunk k-2 is being extracted and the results of chunk k-3 are copied down and handed to
-// the caller's arrays. What Frame::ExtractORB does per image (src/Frame.cc:272-278) for many images in host memory;
-// the transfer over PCIe is what bounds it.
+// A batch of host images as a pipeline of chunks over three streams, one per stage: copies up, kernels, copies down.
+// While chunk k's images are packed into pinned memory by a few host threads (or read straight from the caller's buffer
+// when that is page-locked), chunk k-1 is on its way up, chunk k-2 is being extracted and the results of chunk k-3 come
+// down and are handed to the caller's arrays. What Frame::ExtractORB does per image (src/Frame.cc:272-278) for many
+// images in host memory; the transfer over PCIe is what bounds it, so the copies up follow each other without a gap.
+// (One stream per stage, not one per chunk: streams of a process share a few hardware queues, work on two streams
+// that share one runs in order, and a chunk's copy up would then wait for another chunk's kernels and copy down.)
+// A stage's input buffer is free again when the host has seen the results of the chunk that used it.
 static int extract_host_pipelined(orbhip_extractor* e, const uint8_t* imgs, int nframes, int width, int height,
                                   size_t row_stride, size_t frame_stride, int channels, int rgb, orbhip_keypoint* kp,
                                   uint8_t* desc, int* counts, int cap) {
@@ -1050,17 +1063,17 @@ static int extract_host_pipelined(orbhip_extractor* e, const uint8_t* imgs, int 
     chunk = std::min(chunk, (nframes + 3) / 4);                // four chunks at least, so that the stages overlap
     chunk = std::max(1, std::min(chunk, budget));
     const int nchunks = (nframes + chunk - 1) / chunk;
-    const int nl = std::min(e->host_lanes, nchunks);
+    const int nb = std::min(e->host_lanes, nchunks);           // input buffers: chunks in flight
     const bool pinned = host_pointer_is_pinned(imgs);
     HostStage hs;
-    int rc = host_staging(e, (size_t)nl * chunk * dev_frame, !pinned, nframes, cap, &hs);
+    int rc = host_staging(e, (size_t)nb * chunk * dev_frame, !pinned, nframes, cap, &hs);
     if (rc) return rc;
     // earlier work of this handle (on whatever stream) is over before the workspaces are touched
     if (e->last_stream) HIP_TRY(e, hipEventSynchronize(e->ev_busy));
-    if (e->plan_w != width || e->plan_h != height || e->plan_frames < chunk || e->plan_lanes < nl) {
+    if (e->plan_w != width || e->plan_h != height || e->plan_frames < chunk || e->plan_lanes < 1) {
         HIP_TRY(e, hipDeviceSynchronize());
         const bool same = e->plan_w == width && e->plan_h == height;
-        rc = ensure_plan(e, width, height, std::max(chunk, same ? e->plan_frames : 0), std::max(nl, same ? e->plan_lanes : 0));
+        rc = ensure_plan(e, width, height, std::max(chunk, same ? e->plan_frames : 0), std::max(1, same ? e->plan_lanes : 0));
         if (rc) return rc;
     }
     if (e->d_map_x && (channels != 1 || width != e->map_w || height != e->map_h || width < 2 || height < 2)) {
@@ -1068,53 +1081,87 @@ static int extract_host_pipelined(orbhip_extractor* e, const uint8_t* imgs, int 
         return ORBHIP_ERR_ARG;
     }
     auto fail = [&](int code) { (void)hipDeviceSynchronize(); return code; };   // nothing of this call stays in flight
-    hipStream_t last = e->ws[0].stream;
-    for (int k = 0; k < nchunks + nl; k++) {
-        const int lane = k % nl;
-        Workspace& W = e->ws[lane];
-        if (k >= nl) {                                         // chunk k - nl ran on this lane: its results are down
-            if (hipEventSynchronize(W.done) != hipSuccess) { e->err = "a chunk of the batch failed on the device"; return fail(ORBHIP_ERR_HIP); }
-            const int j0 = (k - nl) * chunk;
+    const hipStream_t s_up = e->ws[0].stream, s_run = e->stream, s_down = e->ws[kLanes - 1].stream;
+    Workspace& W = e->ws[0];                                   // the kernels of all chunks run one after another
+    // ORBHIP_HOST_TRACE=1: where the call's time goes, chunk by chunk (host clock and device events), on stderr
+    const bool trace = e->host_trace;
+    const auto t_call = std::chrono::steady_clock::now();
+    auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
+    std::vector<hipEvent_t> tev;
+    std::vector<double> thost;
+    if (trace) {
+        tev.resize((size_t)nchunks * 4 + 1, nullptr);
+        for (hipEvent_t& ev : tev) (void)hipEventCreate(&ev);
+        thost.assign((size_t)nchunks * 4, 0.0);
+        (void)hipEventRecord(tev[(size_t)nchunks * 4], s_up);
+    }
+    for (int k = 0; k < nchunks + nb; k++) {
+        const int b = k % nb;
+        if (k >= nb) {                                         // chunk k - nb used this buffer: its results are down
+            if (hipEventSynchronize(e->ev_down[b]) != hipSuccess) { e->err = "a chunk of the batch failed on the device"; return fail(ORBHIP_ERR_HIP); }
+            if (trace) thost[(size_t)(k - nb) * 4 + 2] = now_ms();
+            const int j0 = (k - nb) * chunk;
             unpack_frames(hs, j0, std::min(chunk, nframes - j0), cap, kp, desc, counts);
+            if (trace) thost[(size_t)(k - nb) * 4 + 3] = now_ms();
         }
         if (k >= nchunks) continue;
+        if (trace) thost[(size_t)k * 4] = now_ms();
         const int f0 = k * chunk, n = std::min(chunk, nframes - f0);
-        hipStream_t s = W.stream;
-        uint8_t* d_in = e->d_in + (size_t)lane * chunk * dev_frame;
+        uint8_t* d_in = e->d_in + (size_t)b * chunk * dev_frame;
         const uint8_t* src = imgs + (size_t)f0 * frame_stride;
         hipError_t st = hipSuccess;
+        if (!pinned) pack_frames(src, row_stride, frame_stride, e->h_in + (size_t)b * chunk * dev_frame, dev_row, height, width_bytes, n, e->pack_threads);
+        if (trace) (void)hipEventRecord(tev[(size_t)k * 4], s_up);
         if (pinned) {
             if (row_stride == dev_row && frame_stride == dev_frame)
-                st = hipMemcpyAsync(d_in, src, (size_t)n * dev_frame - (dev_row - width_bytes), hipMemcpyHostToDevice, s);
+                st = hipMemcpyAsync(d_in, src, (size_t)n * dev_frame - (dev_row - width_bytes), hipMemcpyHostToDevice, s_up);
             else if (frame_stride == row_stride * (size_t)height)
-                st = hipMemcpy2DAsync(d_in, dev_row, src, row_stride, width_bytes, (size_t)height * n, hipMemcpyHostToDevice, s);
+                st = hipMemcpy2DAsync(d_in, dev_row, src, row_stride, width_bytes, (size_t)height * n, hipMemcpyHostToDevice, s_up);
             else
                 for (int f = 0; f < n && st == hipSuccess; f++)
                     st = hipMemcpy2DAsync(d_in + (size_t)f * dev_frame, dev_row, src + (size_t)f * frame_stride, row_stride, width_bytes,
-                                          (size_t)height, hipMemcpyHostToDevice, s);
+                                          (size_t)height, hipMemcpyHostToDevice, s_up);
         } else {
-            uint8_t* h_in = e->h_in + (size_t)lane * chunk * dev_frame;
-            pack_frames(src, row_stride, frame_stride, h_in, dev_row, height, width_bytes, n);
-            st = hipMemcpyAsync(d_in, h_in, (size_t)n * dev_frame, hipMemcpyHostToDevice, s);
+            st = hipMemcpyAsync(d_in, e->h_in + (size_t)b * chunk * dev_frame, (size_t)n * dev_frame, hipMemcpyHostToDevice, s_up);
         }
+        if (trace) (void)hipEventRecord(tev[(size_t)k * 4 + 1], s_up);
+        if (st == hipSuccess) st = hipEventRecord(e->ev_up[b], s_up);
+        if (st == hipSuccess) st = hipStreamWaitEvent(s_run, e->ev_up[b], 0);
         if (st != hipSuccess) { e->err = std::string("copy of a chunk to the device: ") + hipGetErrorString(st); return fail(ORBHIP_ERR_HIP); }
-        rc = run_pass(e, W, s, d_in, n, dev_row, dev_frame, dev_row, channels, rgb, e->d_out_kp, e->d_out_desc, e->d_out_cnt, cap, f0);
+        rc = run_pass(e, W, s_run, d_in, n, dev_row, dev_frame, dev_row, channels, rgb, e->d_out_kp, e->d_out_desc, e->d_out_cnt, cap, f0);
         if (rc) return fail(rc);
+        if (trace) (void)hipEventRecord(tev[(size_t)k * 4 + 2], s_run);
+        st = hipEventRecord(e->ev_run[b], s_run);
+        if (st == hipSuccess) st = hipStreamWaitEvent(s_down, e->ev_run[b], 0);
         const size_t o = (size_t)f0 * cap;
-        st = hipMemcpyAsync(hs.h_cnt + (size_t)f0 * sizeof(int), e->d_out_cnt + f0, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s);
-        if (st == hipSuccess) st = hipMemcpyAsync(hs.h_kp + o * sizeof(orbhip_keypoint), e->d_out_kp + o * 7, (size_t)n * cap * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, s);
-        if (st == hipSuccess) st = hipMemcpyAsync(hs.h_desc + o * 32, e->d_out_desc + o * 32, (size_t)n * cap * 32, hipMemcpyDeviceToHost, s);
-        if (st == hipSuccess) st = hipEventRecord(W.done, s);
+        if (st == hipSuccess) st = hipMemcpyAsync(hs.h_cnt + (size_t)f0 * sizeof(int), e->d_out_cnt + f0, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s_down);
+        if (st == hipSuccess) st = hipMemcpyAsync(hs.h_kp + o * sizeof(orbhip_keypoint), e->d_out_kp + o * 7, (size_t)n * cap * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, s_down);
+        if (st == hipSuccess) st = hipMemcpyAsync(hs.h_desc + o * 32, e->d_out_desc + o * 32, (size_t)n * cap * 32, hipMemcpyDeviceToHost, s_down);
+        if (trace) (void)hipEventRecord(tev[(size_t)k * 4 + 3], s_down);
+        if (st == hipSuccess) st = hipEventRecord(e->ev_down[b], s_down);
         if (st != hipSuccess) { e->err = std::string("copy of a chunk's results: ") + hipGetErrorString(st); return fail(ORBHIP_ERR_HIP); }
-        last = s;
+        if (trace) thost[(size_t)k * 4 + 1] = now_ms();
     }
-    // every chunk's results are down (the loop waited for each lane's event): the status word of the whole batch
-    HIP_TRY(e, hipMemcpyAsync(hs.h_status, e->d_status, sizeof(int), hipMemcpyDeviceToHost, last));
-    HIP_TRY(e, hipStreamSynchronize(last));
-    e->last_stream = last;
-    HIP_TRY(e, hipEventRecord(e->ev_busy, last));
+    if (trace) {
+        (void)hipDeviceSynchronize();
+        std::fprintf(stderr, "orbhip host batch: %d frames, %d chunks of %d, %d in flight, %s input, %.3f ms\n", nframes, nchunks, chunk, nb,
+                     pinned ? "page-locked" : "pageable", now_ms());
+        std::fprintf(stderr, "  chunk: host [pack+enqueue from..to | results seen, unpacked]   device [copy up from..to, kernels to, copy down to] (ms)\n");
+        for (int k = 0; k < nchunks; k++) {
+            float d[4] = {0, 0, 0, 0};
+            for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&d[i], tev[(size_t)nchunks * 4], tev[(size_t)k * 4 + i]);
+            std::fprintf(stderr, "  %3d: host [%7.3f..%7.3f | %7.3f, %7.3f]   device [%7.3f..%7.3f, %7.3f, %7.3f]\n", k, thost[(size_t)k * 4],
+                         thost[(size_t)k * 4 + 1], thost[(size_t)k * 4 + 2], thost[(size_t)k * 4 + 3], d[0], d[1], d[2], d[3]);
+        }
+        for (hipEvent_t ev : tev) (void)hipEventDestroy(ev);
+    }
+    // every chunk's results are down (the loop waited for each one's event), so the kernels are over: the status word of the whole batch
+    HIP_TRY(e, hipMemcpyAsync(hs.h_status, e->d_status, sizeof(int), hipMemcpyDeviceToHost, s_run));
+    HIP_TRY(e, hipStreamSynchronize(s_run));
+    e->last_stream = s_run;
+    HIP_TRY(e, hipEventRecord(e->ev_busy, s_run));
     collect_timing(e);
-    return host_status(e, hs, last);
+    return host_status(e, hs, s_run);
 }
 
 static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nframes, int width, int height,
@@ -1780,7 +1827,7 @@ int orbhip_extract_stereo_batch(orbhip_extractor* left, orbhip_extractor* right,
     orbhip_extractor* const sides[2] = {left, right};
     const uint8_t* const imgs[2] = {imgs_l, imgs_r};
     for (int k = 0; k < 2; k++) {
-        pack_frames(imgs[k], row_stride, frame_stride, sides[k]->h_in, dev_row, height, (size_t)width, npairs);
+        pack_frames(imgs[k], row_stride, frame_stride, sides[k]->h_in, dev_row, height, (size_t)width, npairs, e->pack_threads);
         HIP_TRY(e, hipMemcpyAsync(sides[k]->d_in, sides[k]->h_in, dev_frame * npairs, hipMemcpyHostToDevice, s));
     }
     rc = orbhip_extract_stereo_batch_device(left, right, left->d_in, right->d_in, npairs, width, height, dev_row, dev_frame,
