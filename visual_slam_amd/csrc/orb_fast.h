@@ -314,9 +314,12 @@ __device__ __forceinline__ void fast_tile(const LevelGeom& g, const uint8_t* __r
     // feeds a scored pixel. PACKED (planes only): no clamp, a band's rows end at most 15 rows below the
     // level, inside the plane; lanes of a band that does not exist read band 0's rows.
     const uint32_t coff = col_ok ? (uint32_t)xg + (PACKED ? (uint32_t)(__mul24(band, FT_ROWS) * pitch) : 0u) : 0u;
+    // Buffer loads: the row's offset is wave-uniform and travels in a scalar register, the lane's offset is a constant
+    // register, so a load costs no vector add. (No range check is wanted from the descriptor: every offset is in
+    // range by construction and far below its 2 GB of records.)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(org), 0, 0x7FFFFFFF, 0x00020000);
     auto load_row = [&](int y) -> uint32_t {
-        const uint32_t off = (uint32_t)((PACKED ? y : min(y, y_last)) * pitch) + coff;   // a frame is far below 4 GB
-        return *reinterpret_cast<const uint32_t*>(org + off);
+        return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)coff, (PACKED ? y : min(y, y_last)) * pitch, 0);
     };
     int pending = 0;                                           // queued pixels not scored yet (wave-uniform, < 128 between steps)
 #pragma unroll 1
@@ -391,7 +394,7 @@ __device__ __forceinline__ void fast_tile(const LevelGeom& g, const uint8_t* __r
         if (__ballot(verdict != 0)) {
             const uint32_t cnt = __popc(verdict);
             const uint32_t incl = wave_scan_incl(cnt);
-            const int total = (int)__shfl(incl, 63, 64);
+            const int total = __builtin_amdgcn_readlane((int)incl, 63);   // wave-uniform by construction: the queue bookkeeping runs on the scalar unit
             const int first = (int)(incl - cnt);
             const uint32_t code0 = ((uint32_t)grp << 11) | ((uint32_t)lane << 5);
             auto drain = [&](int n) {                          // n entries queued: score the full double batches
@@ -483,7 +486,7 @@ __device__ __forceinline__ void fast_tile(const LevelGeom& g, const uint8_t* __r
         if (__ballot(bits != 0)) {
             const uint32_t cnt = __popc(bits);
             const uint32_t incl = wave_scan_incl(cnt);
-            const int total = (int)__shfl(incl, 63, 64);
+            const int total = __builtin_amdgcn_readlane((int)incl, 63);
             const int first = (int)(incl - cnt);
             for (int wb = 0; wb < total; wb += FT_QUEUE) {
                 if (total <= FT_QUEUE) fast_fill_queue<false>(bits, first, 0, (uint32_t)lane << 5, queue);

@@ -784,6 +784,11 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
     for (Workspace& w : e->ws)
         ok = ok && hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&w.done, hipEventDisableTiming) == hipSuccess;
+    // Streams of a process share a few hardware queues (four by default), and work on two streams that share one
+    // runs in order. Measured for the six streams created above, in creation order: the 3rd and 4th share a queue, so
+    // do the 2nd and 5th, the 1st and 6th have one each. The lanes are numbered so that the first two (and the
+    // handle's own stream) lie on different queues.
+    if (ok) std::swap(e->ws[1].stream, e->ws[kLanes - 1].stream);
     for (int k = 0; k < kLanes; k++)
         ok = ok && hipEventCreateWithFlags(&e->ev_up[k], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&e->ev_run[k], hipEventDisableTiming) == hipSuccess &&
@@ -1081,7 +1086,7 @@ static int extract_host_pipelined(orbhip_extractor* e, const uint8_t* imgs, int 
         return ORBHIP_ERR_ARG;
     }
     auto fail = [&](int code) { (void)hipDeviceSynchronize(); return code; };   // nothing of this call stays in flight
-    const hipStream_t s_up = e->ws[0].stream, s_run = e->stream, s_down = e->ws[kLanes - 1].stream;
+    const hipStream_t s_up = e->ws[0].stream, s_run = e->stream, s_down = e->ws[1].stream;   // three different hardware queues
     Workspace& W = e->ws[0];                                   // the kernels of all chunks run one after another
     // ORBHIP_HOST_TRACE=1: where the call's time goes, chunk by chunk (host clock and device events), on stderr
     const bool trace = e->host_trace;
