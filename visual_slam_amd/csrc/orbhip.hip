@@ -143,6 +143,8 @@ struct orbhip_extractor {
     int overlap = 1;               // ORBHIP_OVERLAP=0: FAST of level 0 never runs beside the resize chain on aux_stream; 2: for passes of any size
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_l0 = nullptr, ev_f0 = nullptr;
+    hipEvent_t ev_lv[ORB_MAX_LEVELS] = {};   // level l of the pass on the main stream is complete
+    int fast_split_levels = 2;     // ORBHIP_FAST_SPLIT=n: with `overlap`, the first n levels' FAST tiles are launches of their own
     hipEvent_t ev_up[kLanes] = {}, ev_run[kLanes] = {}, ev_down[kLanes] = {};   // per input buffer of the pipelined host batch call: copied up, extracted, results down
     hipEvent_t ev_busy = nullptr;    // end of the last extraction call: a call on another stream waits for it
     hipEvent_t ev_order = nullptr;   // orders work of another instance (stereo matching) against this one's stream
@@ -605,54 +607,67 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
     // VGA-class images lose a little at any batch size: their seven resize launches are too short to sit beside anything)
     const double px0 = (double)P.lv[0].w * P.lv[0].h;
     const bool beside = e->overlap && nl > 1 && (e->overlap > 1 || (px0 >= kOverlapMinImage && (double)frames * px0 >= kOverlapMinPixels));
-    const unsigned split = beside ? P.fast_cum[0][1] * (unsigned)frames : 0u;
-    if (split) {
+    // With `beside` the plain FAST tiles run on the second stream, level by level as the chain on the main stream
+    // delivers the levels: the first `ksplit` levels as launches of their own, the rest in one launch behind the
+    // chain's last kernel; the packed tiles (the narrow last tile column of every level: a short launch) run on the
+    // main stream behind the chain, beside them. The kernel takes the first tile of its launch as an argument.
+    const int ksplit = beside ? std::min(std::max(e->fast_split_levels, 1), nl) : 0;
+    auto fast_plain = [&](hipStream_t st, int l0, int l1) {    // plain tiles of levels l0 .. l1-1
+        const unsigned first = P.fast_cum[0][l0] * (unsigned)frames, count = P.fast_cum[0][l1] * (unsigned)frames - first;
+        if (!count) return;
+        SpanGuard t(e, st, KC_FAST);
+        hipLaunchKernelGGL(k_fast<false>, dim3(count), dim3(256), 0, st, W.d_pyr, e->d_plan, frames, W.d_seg, W.d_seg_count, e->d_status, first, W.v0);
+    };
+    if (beside) {
         HIP_TRY(e, hipEventRecord(e->ev_l0, s));
         HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->ev_l0, 0));
-        {
-            SpanGuard t(e, e->aux_stream, KC_FAST);
-            hipLaunchKernelGGL(k_fast<false>, dim3(split), dim3(256), 0, e->aux_stream,
-                               W.d_pyr, e->d_plan, frames, W.d_seg, W.d_seg_count, e->d_status, 0u, W.v0);
-        }
-        HIP_TRY(e, hipEventRecord(e->ev_f0, e->aux_stream));
+        fast_plain(e->aux_stream, 0, 1);
     }
     for (int l = 1; l < nl; l++) {
-        SpanGuard t(e, s, KC_RESIZE);
-        const LevelGeom& g = P.lv[l];
-        // (only the level itself: 4-pixel groups ORB_OX / 4 .. c4_end - 1 of the plane's rows ORB_OY .. ORB_OY + h - 1)
-        const int c4_begin = ORB_OX / 4, c4_end = c4_begin + (g.w + 3) / 4;
-        const int nbx = (c4_end + 63) / 64;
-        const dim3 grid(nbx, (g.h + 4 * RS_RPT - 1) / (4 * RS_RPT), frames);
-        if (l == 1 && inplace) {
-            // the source is the caller's image: same kernel, the image's strides in place of the plane's, and the
-            // block columns with a lane whose 12-byte window would pass the readable part of a row run the
-            // clamping code (normally the last one: the right edge and the border columns reflected onto it)
-            LevelGeom gs = P.lv[0];
-            gs.pitch = (int)row_stride;
-            gs.plane_bytes = frame_stride;
-            const uint8_t* src = reinterpret_cast<const uint8_t*>((uintptr_t)d_imgs - ((size_t)ORB_OY * row_stride + ORB_OX));
-            int first_clamp = nbx;
-            for (int c4 = c4_begin; c4 < c4_end && c4 < (int)e->l1_base.size(); c4++)
-                if (e->l1_base[(size_t)c4] + 12 > xlim) { first_clamp = c4 / 64; break; }
-            hipLaunchKernelGGL((k_resize<true, true>), grid, blk2, 0, s, src, W.d_pyr + g.pyr_off, gs, g, e->d_tabs, c4_end, first_clamp, xlim - 12);
-        } else if (g.rs_narrow)
-            hipLaunchKernelGGL((k_resize<true, false>), grid, blk2, 0, s, W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g,
-                               e->d_tabs, c4_end, 0, 0);
-        else
-            hipLaunchKernelGGL((k_resize<false, false>), grid, blk2, 0, s, W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g,
-                               e->d_tabs, c4_end, 0, 0);
+        {
+            SpanGuard t(e, s, KC_RESIZE);
+            const LevelGeom& g = P.lv[l];
+            // (only the level itself: 4-pixel groups ORB_OX / 4 .. c4_end - 1 of the plane's rows ORB_OY .. ORB_OY + h - 1)
+            const int c4_begin = ORB_OX / 4, c4_end = c4_begin + (g.w + 3) / 4;
+            const int nbx = (c4_end + 63) / 64;
+            const dim3 grid(nbx, (g.h + 4 * RS_RPT - 1) / (4 * RS_RPT), frames);
+            if (l == 1 && inplace) {
+                // the source is the caller's image: same kernel, the image's strides in place of the plane's, and the
+                // block columns with a lane whose 12-byte window would pass the readable part of a row run the
+                // clamping code (normally the last one: the right edge and the border columns reflected onto it)
+                LevelGeom gs = P.lv[0];
+                gs.pitch = (int)row_stride;
+                gs.plane_bytes = frame_stride;
+                const uint8_t* src = reinterpret_cast<const uint8_t*>((uintptr_t)d_imgs - ((size_t)ORB_OY * row_stride + ORB_OX));
+                int first_clamp = nbx;
+                for (int c4 = c4_begin; c4 < c4_end && c4 < (int)e->l1_base.size(); c4++)
+                    if (e->l1_base[(size_t)c4] + 12 > xlim) { first_clamp = c4 / 64; break; }
+                hipLaunchKernelGGL((k_resize<true, true>), grid, blk2, 0, s, src, W.d_pyr + g.pyr_off, gs, g, e->d_tabs, c4_end, first_clamp, xlim - 12);
+            } else if (g.rs_narrow)
+                hipLaunchKernelGGL((k_resize<true, false>), grid, blk2, 0, s, W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g,
+                                   e->d_tabs, c4_end, 0, 0);
+            else
+                hipLaunchKernelGGL((k_resize<false, false>), grid, blk2, 0, s, W.d_pyr + P.lv[l - 1].pyr_off, W.d_pyr + g.pyr_off, P.lv[l - 1], g,
+                                   e->d_tabs, c4_end, 0, 0);
+        }
         if (int rc = debug_sync_point(e, s, "k_resize")) return rc;
+        if (beside && (l < ksplit || l == nl - 1)) {           // level l is there (l == nl - 1: all of them)
+            HIP_TRY(e, hipEventRecord(e->ev_lv[l], s));
+            HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->ev_lv[l], 0));
+            if (l < ksplit) fast_plain(e->aux_stream, l, l + 1);
+            if (l == nl - 1 && ksplit < nl) fast_plain(e->aux_stream, std::max(ksplit, 1), nl);
+        }
     }
-    {                                                          // all (remaining) levels in one launch per kind of tile
+    if (!beside) fast_plain(s, 0, nl);
+    if (P.fast_cum[1][nl]) {
         SpanGuard t(e, s, KC_FAST);
-        if (P.fast_cum[0][nl] * (unsigned)frames > split)
-            hipLaunchKernelGGL(k_fast<false>, dim3(P.fast_cum[0][nl] * (unsigned)frames - split), dim3(256), 0, s,
-                               W.d_pyr, e->d_plan, frames, W.d_seg, W.d_seg_count, e->d_status, split, W.v0);
-        if (P.fast_cum[1][nl])
-            hipLaunchKernelGGL(k_fast<true>, dim3(P.fast_cum[1][nl] * (unsigned)frames), dim3(256), 0, s,
-                               W.d_pyr, e->d_plan, frames, W.d_seg, W.d_seg_count, e->d_status, 0u, W.v0);
+        hipLaunchKernelGGL(k_fast<true>, dim3(P.fast_cum[1][nl] * (unsigned)frames), dim3(256), 0, s,
+                           W.d_pyr, e->d_plan, frames, W.d_seg, W.d_seg_count, e->d_status, 0u, W.v0);
     }
-    if (split) HIP_TRY(e, hipStreamWaitEvent(s, e->ev_f0, 0));
+    if (beside) {
+        HIP_TRY(e, hipEventRecord(e->ev_f0, e->aux_stream));
+        HIP_TRY(e, hipStreamWaitEvent(s, e->ev_f0, 0));
+    }
     if (int rc = debug_sync_point(e, s, "k_fast")) return rc;
     {
         SpanGuard t(e, s, KC_QUADTREE);
@@ -778,6 +793,7 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
     bool ok = hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&e->ev_l0, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&e->ev_f0, hipEventDisableTiming) == hipSuccess &&
+
               hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&e->ev_busy, hipEventDisableTiming) == hipSuccess;
@@ -789,6 +805,7 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
     // do the 2nd and 5th, the 1st and 6th have one each. The lanes are numbered so that the first two (and the
     // handle's own stream) lie on different queues.
     if (ok) std::swap(e->ws[1].stream, e->ws[kLanes - 1].stream);
+    for (hipEvent_t& ev : e->ev_lv) ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
     for (int k = 0; k < kLanes; k++)
         ok = ok && hipEventCreateWithFlags(&e->ev_up[k], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&e->ev_run[k], hipEventDisableTiming) == hipSuccess &&
@@ -799,6 +816,7 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
     if (const char* v = std::getenv("ORBHIP_DEBUG_SYNC")) e->debug_sync = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_LANES")) e->max_lanes = std::min(kLanes, std::max(1, std::atoi(v)));
     if (const char* v = std::getenv("ORBHIP_OVERLAP")) e->overlap = std::min(2, std::max(0, std::atoi(v)));
+    if (const char* v = std::getenv("ORBHIP_FAST_SPLIT")) e->fast_split_levels = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("ORBHIP_INPLACE_LEVEL0")) e->inplace_l0 = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_FAST_PACK")) e->fast_pack = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_GRAPH")) e->use_graph = std::atoi(v) != 0;
@@ -839,6 +857,7 @@ int orbhip_destroy(orbhip_extractor* e) {
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_l0) (void)hipEventDestroy(e->ev_l0);
     if (e->ev_f0) (void)hipEventDestroy(e->ev_f0);
+    for (hipEvent_t ev : e->ev_lv) if (ev) (void)hipEventDestroy(ev);
     if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
     if (e->ev_order) (void)hipEventDestroy(e->ev_order);
     if (e->ev_busy) (void)hipEventDestroy(e->ev_busy);
