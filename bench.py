@@ -267,12 +267,15 @@ def main():
     dt = time.perf_counter() - t0
     ex.synchronize()   # raises on a deferred capacity error
     timing = ex.timing()
+    busy = ex.timing_busy()
     ex.enable_timing(False)
     if args.stereo:
         exr.synchronize()
         tr = exr.timing()
+        br = exr.timing_busy()
         exr.enable_timing(False)
         timing = {k: (timing[k][0] + tr[k][0], timing[k][1] + tr[k][1]) for k in timing}
+        busy = {k: busy[k] + br[k] for k in busy}
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -290,13 +293,15 @@ def main():
             total_bytes = sum(parts.values())
         else:
             parts["k_stereo"] = 0
-        kname = max(timing, key=lambda k: timing[k][0])
-        k_ms, k_launches = timing[kname]
+        # (busy: the time during which at least one launch of the class ran; launches of a class that run side by side
+        # on two streams count once)
+        kname = max(busy, key=lambda k: busy[k])
+        k_ms, k_launches = busy[kname], timing[kname][1]
         lanes = max(1, min(int(os.environ.get("ORBHIP_LANES", "1")), 4))
         passes = max(timing["k_quadtree"][1] // (2 if args.stereo else 1), 1)   # one quadtree launch per pass and side
         frames_per_launch = B * args.steps / passes
-        # A "launch" below is what a kernel class launches for one pass (k_fast: level 0 on the second stream, the other
-        # levels' plain tiles and the packed tiles; k_resize: the seven levels of the chain): bytes and time of a pass.
+        # A "launch" below is what a kernel class launches for one pass (k_fast: the plain tiles level by level on the
+        # second stream and the packed tiles; k_resize: the seven levels of the chain): bytes and time of a pass.
         k_bytes_per_launch = parts[kname] * frames_per_launch
         k_avg_s = k_ms * 1e-3 / passes
         achieved = k_bytes_per_launch / k_avg_s / 1e9
@@ -308,14 +313,15 @@ def main():
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": int(k_bytes_per_launch), "avg_launch_ms": round(k_avg_s * 1e3, 4),
-                    "launch_is": "the launches of the kernel class for one pass (%.1f timed spans per pass)" % (k_launches / passes),
+                    "launch_is": "the launches of the kernel class for one pass (%.1f timed spans per pass; time = that during which at least one of them ran)" % (k_launches / passes),
+                    "timed": "as run",
                     "whole_path_bytes_per_frame": int(total_bytes),
                     "whole_path_frac": round(B * args.steps / dt * total_bytes / 1e9 / HBM_PEAK_GBS, 4),
                     "compulsory_bytes_per_frame": int(compulsory_bytes(w, h, scale, levels, nfeat)),
                     "device_copy_GBs": round(copy_gbs, 1),
                     "whole_path_frac_of_copy": round(B * args.steps / dt * total_bytes / 1e9 / copy_gbs, 4),
                     "frames_per_pass": int(frames_per_launch), "passes_in_flight": lanes,
-                    "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in timing.items()}}
+                    "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in busy.items()}}
         # the limit that actually binds the dominant kernel: vector-ALU issue. Measured on this chip
         # (tools/calib/valu_calib.hip, profiles/r02_valu_calib.txt): with 2..8 waves per SIMD a SIMD needs
         # 4.25 cycles per wave64 instruction for packed 16-bit, 3-operand, DPP, SDWA, multiply and
@@ -336,13 +342,15 @@ def main():
                                 "peak_insts_per_s": peak_arch, "cycles_per_inst_peak": 4.0, "frac": round(valu / k_avg_s / peak_arch, 4),
                                 "cycles_per_inst_calibrated": VALU_CYCLES_PER_INST, "calibration": "profiles/r02_valu_calib.txt",
                                 "frac_at_calibrated_4.25": round(valu / k_avg_s / peak_cal, 4)}
-        # By default level 0's FAST runs on a second stream beside the resize chain (ORBHIP_OVERLAP, passes of 32 frames
-        # and more), and ORBHIP_LANES > 1 keeps several passes in flight: the launch durations above are then those of
-        # kernels that share the chip. Also time the same kernels one at a time (a second handle with both switched
-        # off, two untimed steps): a kernel with the GPU to itself.
+        # By default FAST runs on a second stream beside the resize chain, level by level (ORBHIP_OVERLAP, large passes),
+        # and ORBHIP_LANES > 1 keeps several passes in flight: the launch durations above are then those of kernels that
+        # share the chip. The same kernels are then also timed one at a time (a second handle with both switched off,
+        # one untimed and two timed steps): a kernel with the GPU to itself. That is the figure the roofline object
+        # leads with (it says what the kernel achieves, and it is what a kernel trace of ORBHIP_OVERLAP=0 shows); the
+        # figures as run move to "as_run".
         ov = os.environ.get("ORBHIP_OVERLAP", "1")
         overlap_on = not args.stereo and (ov == "2" or (ov != "0" and w * h >= 4.0e5 and frames_per_launch * w * h >= 2.0e8))   # the library's own rule
-        roofline["level0_fast_beside_resize"] = bool(overlap_on)
+        roofline["fast_beside_resize"] = bool(overlap_on)
         if (lanes > 1 or overlap_on) and not args.skip_alone:
             saved = {k: os.environ.get(k) for k in ("ORBHIP_LANES", "ORBHIP_OVERLAP")}
             os.environ["ORBHIP_LANES"] = "1"
@@ -373,10 +381,24 @@ def main():
             s_passes = max(t1["k_quadtree"][1], 1)
             s_bytes = parts[kname] * B * 2 / s_passes
             s_avg = s_ms * 1e-3 / s_passes
-            roofline["kernels_one_at_a_time"] = {"achieved": round(s_bytes / s_avg / 1e9, 1), "frac": round(s_bytes / s_avg / 1e9 / HBM_PEAK_GBS, 4),
-                                                 "bytes_per_launch": int(s_bytes), "avg_launch_ms": round(s_avg * 1e3, 4),
-                                                 "kernel_ms_per_step": {k: round(v[0] / 2, 3) for k, v in t1.items()},
-                                                 "ms_per_step": round(sum(v[0] for v in t1.values()) / 2, 3)}
+            alone = {"achieved": round(s_bytes / s_avg / 1e9, 1), "frac": round(s_bytes / s_avg / 1e9 / HBM_PEAK_GBS, 4),
+                     "bytes_per_launch": int(s_bytes), "avg_launch_ms": round(s_avg * 1e3, 4),
+                     "kernel_ms_per_step": {k: round(v[0] / 2, 3) for k, v in t1.items()},
+                     "ms_per_step": round(sum(v[0] for v in t1.values()) / 2, 3)}
+            roofline["as_run"] = {k: roofline[k] for k in ("achieved", "frac", "avg_launch_ms", "launch_is", "kernel_ms_per_step")}
+            roofline["as_run"]["note"] = ("kernels share the chip: FAST beside the resize chain" +
+                                          (", %d passes in flight" % lanes if lanes > 1 else ""))
+            roofline.update({"achieved": alone["achieved"], "frac": alone["frac"], "avg_launch_ms": alone["avg_launch_ms"],
+                             "kernel_ms_per_step": alone["kernel_ms_per_step"], "kernel_ms_sum_per_step": alone["ms_per_step"],
+                             "timed": "one kernel at a time (a second handle with ORBHIP_OVERLAP=0 and ORBHIP_LANES=1 in this process, "
+                                      "HIP events on the kernels' stream, two steps)",
+                             "launch_is": "the launches of the kernel class for one pass (%.1f per pass), one after the other" % (s_launches / s_passes)})
+            if "valu" in roofline:
+                v = roofline["valu"]
+                v["as_run_frac"] = v["frac"]
+                v["achieved_insts_per_s"] = round(v["wave_insts_per_launch"] / s_avg, 1)
+                v["frac"] = round(v["wave_insts_per_launch"] / s_avg / v["peak_insts_per_s"], 4)
+                v["frac_at_calibrated_4.25"] = round(v["wave_insts_per_launch"] / s_avg / (256 * 4 / VALU_CYCLES_PER_INST * 2.4e9), 4)
             del ex1
         cpu = None
         if args.cpu_frames < 0:

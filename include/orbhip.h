@@ -194,6 +194,10 @@ int orbhip_debug_logf(orbhip_extractor* e, uint32_t first_bits, uint32_t count, 
  * number of kernel classes. Enabling adds event records (and a wait in this call) only. */
 int orbhip_enable_timing(orbhip_extractor* e, int on);
 int orbhip_get_timing(orbhip_extractor* e, const char** names, float* ms, int* launches, int cap);
+/* The same classes: the time during which at least one launch of the class was running. Launches of one class
+ * can run side by side on two internal streams (FAST follows the resize chain level by level), and then the sum
+ * that orbhip_get_timing reports counts that time more than once. (No counterpart in the reference.) */
+int orbhip_get_timing_busy(orbhip_extractor* e, float* busy_ms, int cap);
 
 /* Rectification in front of the extraction: cv::remap(im, imRect, M1, M2, cv::INTER_LINEAR) as the
  * stereo mains apply it to both images of every frame (Examples/Stereo/stereo_euroc.cc:136-137,

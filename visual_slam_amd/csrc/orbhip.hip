@@ -199,6 +199,7 @@ struct orbhip_extractor {
     std::vector<TimedSpan> spans;
     std::vector<hipEvent_t> event_pool;
     float kc_ms[KC_COUNT] = {0};
+    float kc_busy_ms[KC_COUNT] = {0};
     int kc_launches[KC_COUNT] = {0};
 };
 
@@ -722,9 +723,28 @@ int check_status(orbhip_extractor* e) {
 }
 
 void collect_timing(orbhip_extractor* e) {
+    // kc_ms: the spans of a class added up; kc_busy_ms: the time during which at least one span of the class was open
+    // (launches of one class run side by side on two streams when FAST follows the resize chain level by level)
+    std::vector<std::pair<float, float>> iv[KC_COUNT];
+    const hipEvent_t base = e->spans.empty() ? nullptr : e->spans[0].a;
     for (TimedSpan& sp : e->spans) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) e->kc_ms[sp.kc] += ms;
+        float ms = 0, ta = 0;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+            e->kc_ms[sp.kc] += ms;
+            if (hipEventElapsedTime(&ta, base, sp.a) == hipSuccess) iv[sp.kc].emplace_back(ta, ta + ms);
+            else e->kc_busy_ms[sp.kc] += ms;
+        }
+    }
+    for (int kc = 0; kc < KC_COUNT; kc++) {
+        std::sort(iv[kc].begin(), iv[kc].end());
+        float lo = 0, hi = -1;
+        for (const auto& x : iv[kc]) {
+            if (hi < lo || x.first > hi) { if (hi >= lo) e->kc_busy_ms[kc] += hi - lo; lo = x.first; hi = x.second; }
+            else hi = std::max(hi, x.second);
+        }
+        if (hi >= lo) e->kc_busy_ms[kc] += hi - lo;
+    }
+    for (TimedSpan& sp : e->spans) {
         e->event_pool.push_back(sp.a);
         e->event_pool.push_back(sp.b);
     }
@@ -1530,6 +1550,7 @@ int orbhip_enable_timing(orbhip_extractor* e, int on) {
     if (!e) return ORBHIP_ERR_ARG;
     e->timing = on != 0;
     std::memset(e->kc_ms, 0, sizeof(e->kc_ms));
+    std::memset(e->kc_busy_ms, 0, sizeof(e->kc_busy_ms));
     std::memset(e->kc_launches, 0, sizeof(e->kc_launches));
     return ORBHIP_OK;
 }
@@ -1544,6 +1565,16 @@ int orbhip_get_timing(orbhip_extractor* e, const char** names, float* ms, int* l
         if (ms) ms[i] = e->kc_ms[i];
         if (launches) launches[i] = e->kc_launches[i];
     }
+    return KC_COUNT;
+}
+
+int orbhip_get_timing_busy(orbhip_extractor* e, float* busy_ms, int cap) {
+    if (!e) return ORBHIP_ERR_ARG;
+    DeviceScope device_scope(e->device);
+    (void)hipDeviceSynchronize();
+    collect_timing(e);
+    for (int i = 0; i < KC_COUNT && i < cap; i++)
+        if (busy_ms) busy_ms[i] = e->kc_busy_ms[i];
     return KC_COUNT;
 }
 

@@ -29,7 +29,7 @@ EXPORTS = [
     "orbhip_get_scale_factor", "orbhip_get_scale_factors", "orbhip_get_inverse_scale_factors",
     "orbhip_get_scale_sigma_squares", "orbhip_get_inverse_scale_sigma_squares",
     "orbhip_get_features_per_level", "orbhip_get_umax", "orbhip_pyramid_info", "orbhip_pyramid_copy",
-    "orbhip_debug_candidates", "orbhip_debug_level_keypoints", "orbhip_enable_timing", "orbhip_get_timing", "orbhip_strerror",
+    "orbhip_debug_candidates", "orbhip_debug_level_keypoints", "orbhip_enable_timing", "orbhip_get_timing", "orbhip_get_timing_busy", "orbhip_strerror",
     "orbhip_last_error", "orbhip_stereo_match", "orbhip_stereo_match_batch_device",
     "orbhip_stereo_match_batch_device_noalloc", "orbhip_extract_stereo_batch_device",
     "orbhip_extract_color", "orbhip_extract_batch_device_color",
@@ -94,6 +94,7 @@ def lib():
         L.orbhip_debug_level_keypoints.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
         L.orbhip_enable_timing.argtypes = [vp, C.c_int]
         L.orbhip_get_timing.argtypes = [vp, C.POINTER(C.c_char_p), fp, ip, C.c_int]
+        L.orbhip_get_timing_busy.argtypes = [vp, fp, C.c_int]
         L.orbhip_strerror.argtypes = [C.c_int]
         L.orbhip_strerror.restype = C.c_char_p
         L.orbhip_last_error.argtypes = [vp]
@@ -645,3 +646,12 @@ class ORBextractor:
         launches = (C.c_int * 16)()
         n = lib().orbhip_get_timing(self._h, names, ms, launches, 16)
         return {names[i].decode(): (ms[i], launches[i]) for i in range(n)}
+
+    def timing_busy(self):
+        """Per kernel class: milliseconds during which at least one of its launches was running (launches of a
+        class can run side by side on two streams; `timing()` adds their durations up)."""
+        names = (C.c_char_p * 16)()
+        busy = (C.c_float * 16)()
+        n = lib().orbhip_get_timing(self._h, names, None, None, 16)
+        lib().orbhip_get_timing_busy(self._h, busy, 16)
+        return {names[i].decode(): busy[i] for i in range(n)}
