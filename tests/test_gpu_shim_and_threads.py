@@ -57,8 +57,9 @@ def test_two_instances_on_two_threads_like_stereo():
 @pytest.mark.gpu
 def test_two_passes_in_flight_give_the_same_results():
     """ORBHIP_LANES=2 splits a large batch into passes on two internal streams, ORBHIP_OVERLAP=1 (the default
-    for large passes; ORBHIP_OVERLAP=2 forces it for any size) runs level 0's FAST beside the resize chain on a second stream (both read
-    at handle creation, so they run in child processes); the outputs must equal the single-stream ones."""
+    for large passes; ORBHIP_OVERLAP=2 forces it for any size) runs FAST on a second stream beside the resize chain,
+    the first ORBHIP_FAST_SPLIT levels as launches of their own (all read at handle creation, so they run in child
+    processes); the outputs must equal the single-stream ones."""
     import os
     import subprocess
     import sys
@@ -77,14 +78,15 @@ def test_two_passes_in_flight_give_the_same_results():
     ) % str(root)
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
-        for lanes, overlap in (("1", "0"), ("2", "0"), ("1", "2"), ("2", "2")):
-            path = os.path.join(tmp, "lanes%s_%s.npz" % (lanes, overlap))
+        for lanes, overlap, split in (("1", "0", "2"), ("2", "0", "2"), ("1", "2", "2"), ("2", "2", "2"), ("1", "2", "1"), ("1", "2", "4"),
+                                      ("2", "2", "16")):
+            path = os.path.join(tmp, "lanes%s_%s_%s.npz" % (lanes, overlap, split))
             # (the host batch call in one piece, so that it runs as passes of 64 and 16 frames through the device entry point)
-            env = dict(os.environ, ORBHIP_LANES=lanes, ORBHIP_OVERLAP=overlap, ORBHIP_HOST_PIPELINE="0")
+            env = dict(os.environ, ORBHIP_LANES=lanes, ORBHIP_OVERLAP=overlap, ORBHIP_FAST_SPLIT=split, ORBHIP_HOST_PIPELINE="0")
             subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=240)
             with np.load(path) as z:
-                out[lanes + overlap] = {k: z[k] for k in z.files}
-    assert out["10"]["n"].sum() > 80 * 100
-    for mode in ("20", "12", "22"):
+                out[lanes + overlap + "/" + split] = {k: z[k] for k in z.files}
+    assert out["10/2"]["n"].sum() > 80 * 100
+    for mode in out:
         for k in ("n", "kp", "desc"):
-            assert np.array_equal(out["10"][k], out[mode][k]), (mode, k)
+            assert np.array_equal(out["10/2"][k], out[mode][k]), (mode, k)
