@@ -479,8 +479,7 @@ __device__ __forceinline__ void fast_tile(const LevelGeom& g, const uint8_t* __r
             for (int j = 0; j < 8; j++) {
                 const uint32_t v = *reinterpret_cast<const uint32_t*>(&s_map[(mh + j) * FT_P + 4 * lane]);
                 const uint32_t nz = (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;   // bit 7 of every non-zero byte
-                const uint32_t nib = ((nz >> 7) & 1u) | ((nz >> 14) & 2u) | ((nz >> 21) & 4u) | ((nz >> 28) & 8u);
-                bits |= nib << (4 * j);
+                bits |= nz >> (7 - j);                         // bit 8 * pixel + row
             }
         }
         if (__ballot(bits != 0)) {
@@ -494,8 +493,8 @@ __device__ __forceinline__ void fast_tile(const LevelGeom& g, const uint8_t* __r
                 const int nw = min(FT_QUEUE, total - wb);
                 for (int q = 0; q < nw; q += 64) {
                     const bool have = q + lane < nw;
-                    const uint32_t e = have ? queue[q + lane] : 0u;       // lane << 5 | 4 * row + pixel
-                    nms_emit(have, (int)((e >> 3) & 0xFC) + (int)(e & 3), mh + (int)((e >> 2) & 7));
+                    const uint32_t e = have ? queue[q + lane] : 0u;       // lane << 5 | 8 * pixel + row
+                    nms_emit(have, (int)((e >> 3) & 0xFC) + (int)((e >> 3) & 3), mh + (int)(e & 7));
                 }
             }
         }
