@@ -97,6 +97,25 @@ def test_pipelined_host_batch_from_pinned_memory():
     _same(g.extract_batch(pinned.numpy()), ref)
 
 
+def test_pipelined_host_batch_from_pinned_views():
+    """Page-locked images that are views into a wider buffer (row stride larger than the width), with and without a gap
+    between the frames: the two strided copy routes of the pipeline, and the trace switch that prints its timeline."""
+    import torch
+    from visual_slam_amd import orbhip
+    big = torch.from_numpy(np.stack([synth.frame("blocks", 400, 260, 500 + i) for i in range(12)])).pin_memory().numpy()
+    g = _with_env({"ORBHIP_HOST_TRACE": "1"}, lambda: orbhip.ORBextractor(*PRM))
+    for y0, y1 in ((0, 260), (9, 249)):                         # frames one behind the other / with rows between them
+        roi = big[:, y0:y1, 31:364]                             # 333 columns, row stride 400
+        h = y1 - y0
+        ref = _singles(orbhip, [np.ascontiguousarray(r) for r in roi])
+        cap = g.max_keypoints(333, h)
+        kp = np.zeros((12, cap), orbhip.KP_DTYPE); desc = np.zeros((12, cap, 32), np.uint8); cnt = np.zeros(12, np.int32)
+        rc = orbhip.lib().orbhip_extract_batch(g._h, roi.ctypes.data, 12, 333, h, roi.strides[1], roi.strides[0],
+                                               kp.ctypes.data, desc.ctypes.data, cnt.ctypes.data, cap)
+        assert rc == 0, orbhip.lib().orbhip_last_error(g._h)
+        _same([(kp[i, :cnt[i]], desc[i, :cnt[i]]) for i in range(12)], ref)
+
+
 def test_capacity_error_is_reported_by_the_pipeline():
     from visual_slam_amd import orbhip
     imgs = _frames(10)
