@@ -69,8 +69,9 @@ const int kLanes = 4;
 // against 0.336, 1080p / 2000 1.13 against 0.82
 const int kQtSmallQuota = 300;
 const int kQtLatencyGroups = 256;   // (frames x levels) up to this: a pass that cannot fill the chip
-const double kOverlapMinPixels = 2.0e8;   // passes of at least this many input pixels, of images of at least kOverlapMinImage pixels,
-const double kOverlapMinImage = 4.0e5;    // run level 0's FAST on a second stream beside the resize chain
+const double kOverlapMinPixels = 5.0e7;   // passes of at least this many input pixels run FAST on a second stream beside the resize chain;
+const double kOverlapMinPixelsPair = 2.0e8, kOverlapMinImagePair = 4.0e5;   // the two sides of a stereo batch, one after the other on one
+                                                                            // stream: larger passes of images of at least this size only
 const int kMinLaneFrames = 16;     // batches below twice this run as one pass on the caller's stream
 const int kPipelineMinFrames = 8;  // host batches from this size on are cut into chunks that overlap copy, extraction and copy back
 
@@ -140,6 +141,7 @@ struct orbhip_extractor {
     int fast_pack = 1;             // ORBHIP_FAST_PACK=0: every tile of k_fast is a plain one (no bands in the last tile column)
     int inplace_l0 = 1;            // ORBHIP_INPLACE_LEVEL0=0: always copy gray input into the level-0 plane
     std::vector<int> l1_base;      // per 4-pixel group of level 1's plane: 4-aligned first source column of its taps
+    bool in_pair = false;          // set around the passes of a stereo batch call (the overlap rule differs)
     int overlap = 1;               // ORBHIP_OVERLAP=0: FAST of level 0 never runs beside the resize chain on aux_stream; 2: for passes of any size
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_l0 = nullptr, ev_f0 = nullptr;
@@ -601,13 +603,15 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
         if (!inplace) launch_level0(e, W, s, d_imgs, frames, row_stride, frame_stride, channels, rgb, true);
     }
     if (int rc = debug_sync_point(e, s, "level 0")) return rc;
-    // FAST is bound by vector issue, the resize chain by memory: with `overlap` level 0's FAST runs on
-    // a second stream beside the chain and the remaining levels follow on the main stream
-    // (measured per pass: 1080p x 128 frames +1.7 %, x 1024 +2.8 %, 4K x 128 +1.7 %, 1241 x 376 x 1024 +1.5 %, VGA x 1024 +0.4 %;
-    // 1080p x 64 -1 %, 752 x 480 x 512 -1.1 %, VGA x 64 -5 %: the fork and join cost more than a short chain can hide;
-    // VGA-class images lose a little at any batch size: their seven resize launches are too short to sit beside anything)
+    // FAST is bound by vector issue, the resize chain by memory: with `overlap` FAST runs on a second stream beside
+    // the chain, level by level (below). Measured per pass against one stream: 1080p x 1024 frames +4 to +6 %, x 64 +4 %,
+    // x 32 +2 %, x 16 +1 %, x 8 -2 %; 1241 x 376 x 1024 +6 %, x 32 -5 %; VGA x 1024 +2 to +3 %, x 256 +2 %, x 64 -3 %, x 16 -10 %:
+    // the fork and join cost more than a short chain can hide, hence the smallest pass. The two sides of a stereo batch
+    // (752 x 480 x 512 pairs -2 %, x 64 pairs -12 %, 1080p x 256 pairs +0.5 %) keep the rule of large passes of large images.
     const double px0 = (double)P.lv[0].w * P.lv[0].h;
-    const bool beside = e->overlap && nl > 1 && (e->overlap > 1 || (px0 >= kOverlapMinImage && (double)frames * px0 >= kOverlapMinPixels));
+    const bool large = e->in_pair ? px0 >= kOverlapMinImagePair && (double)frames * px0 >= kOverlapMinPixelsPair
+                                  : (double)frames * px0 >= kOverlapMinPixels;
+    const bool beside = e->overlap && nl > 1 && (e->overlap > 1 || large);
     // With `beside` the plain FAST tiles run on the second stream, level by level as the chain on the main stream
     // delivers the levels: the first `ksplit` levels as launches of their own, the rest in one launch behind the
     // chain's last kernel; the packed tiles (the narrow last tile column of every level: a short launch) run on the
@@ -1782,6 +1786,11 @@ int orbhip_extract_stereo_batch_device(orbhip_extractor* left, orbhip_extractor*
     }
     int rc = stereo_scratch(left, chunk, cap);
     if (rc) return rc;
+    struct PairScope {                                         // the passes below are those of a stereo pair
+        orbhip_extractor *a, *b;
+        PairScope(orbhip_extractor* l, orbhip_extractor* r) : a(l), b(r) { a->in_pair = b->in_pair = true; }
+        ~PairScope() { a->in_pair = b->in_pair = false; }
+    } pair_scope(left, right);
     for (int f0 = 0; f0 < nframes; f0 += chunk) {
         const int n = std::min(chunk, nframes - f0);
         rc = run_pass(left, left->ws[0], s, d_imgs_l + (size_t)f0 * frame_stride, n, row_stride, frame_stride, (size_t)width, 1, 0,
