@@ -100,10 +100,11 @@ int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int 
  * chunks (about 64 MB of images each, ORBHIP_HOST_CHUNK=n frames overrides) over three internal streams, one
  * per stage: while one chunk is packed into page-locked memory by a few host threads (ORBHIP_PACK_THREADS,
  * default half of the CPUs the process may use, at most 4), the previous one travels to the device, the one
- * before is extracted and the results of the one before that travel back (ORBHIP_HOST_LANES=2..4 chunks in
- * flight, default 3; ORBHIP_HOST_TRACE=1 prints the timeline of a call on stderr). Images that already lie in
- * page-locked memory (hipHostMalloc / hipHostRegister) are copied from where they are, without the packing
- * step. ORBHIP_HOST_PIPELINE=0 (read by orbhip_create) restores one copy up, all passes, one copy down.
+ * before is extracted and the results of the one before that travel back and are handed to the caller's arrays
+ * by helper threads (ORBHIP_HOST_LANES=2..4 chunks in flight, default 3; ORBHIP_HOST_TRACE=1 prints the timeline
+ * of a call on stderr). Images that already lie in page-locked memory (hipHostMalloc / hipHostRegister) with rows
+ * of the staging pitch (the width rounded up to 16 bytes, frames one behind the other) are copied from where
+ * they are, without the packing step. ORBHIP_HOST_PIPELINE=0 (read by orbhip_create) restores one copy up, all passes, one copy down.
  * After the call orbhip_pyramid_copy sees the frames of the last chunk only. */
 int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int nframes, int width, int height,
                          size_t row_stride, size_t frame_stride, orbhip_keypoint* kp, uint8_t* desc,
@@ -260,7 +261,9 @@ int orbhip_extract_stereo_batch_device(orbhip_extractor* left, orbhip_extractor*
                                        orbhip_keypoint* d_kp_r, uint8_t* d_desc_r, int* d_cnt_r, int cap,
                                        float mb, float mbf, float* d_uright, float* d_depth, int* d_nmatch, void* stream);
 /* The same for pairs in host memory, results into host arrays ([npairs][cap] records per side, [npairs][cap]
- * floats of mvuRight / mvDepth, nmatch[npairs] or NULL); waits for the results. */
+ * floats of mvuRight / mvDepth, nmatch[npairs] or NULL); waits for the results. From 8 pairs on it runs as the
+ * chunk pipeline of orbhip_extract_batch (a chunk: pairs whose two sides together are about 64 MB of images; the
+ * same environment switches). Afterwards a separate matching call finds the pyramids of the last chunk only. */
 int orbhip_extract_stereo_batch(orbhip_extractor* left, orbhip_extractor* right, const uint8_t* imgs_l, const uint8_t* imgs_r,
                                 int npairs, int width, int height, size_t row_stride, size_t frame_stride,
                                 orbhip_keypoint* kp_l, uint8_t* desc_l, int* cnt_l, orbhip_keypoint* kp_r, uint8_t* desc_r, int* cnt_r,

@@ -99,7 +99,8 @@ def test_pipelined_host_batch_from_pinned_memory():
 
 def test_pipelined_host_batch_from_pinned_views():
     """Page-locked images that are views into a wider buffer (row stride larger than the width), with and without a gap
-    between the frames: the two strided copy routes of the pipeline, and the trace switch that prints its timeline."""
+    between the frames: packed by the host threads like pageable ones (only the staging layout is copied from where it
+    lies); the trace switch that prints the timeline is on."""
     import torch
     from visual_slam_amd import orbhip
     big = torch.from_numpy(np.stack([synth.frame("blocks", 400, 260, 500 + i) for i in range(12)])).pin_memory().numpy()
@@ -190,6 +191,46 @@ def test_stereo_host_batch_and_multi():
     check(orbhip.extract_stereo_batch(lefts, rights, L, R, BF / FX, BF))
     with pytest.raises(orbhip.OrbHipError):
         orbhip.extract_stereo_batch(hL, hL, L, R, BF / FX, BF)  # one instance cannot be both sides
+
+
+def test_stereo_host_batch_pipelined():
+    """Thirteen pairs in host memory in chunks of three (five chunks over three input buffers, the last one short),
+    from pageable and from page-locked memory, and in one piece, against the per-pair calls; then the pyramids of the
+    last chunk are still there for a separate matching call."""
+    import torch
+    from visual_slam_amd import orbhip
+    prm = (600, 1.2, 8, 20, 7)
+    pairs = [synth.stereo_pair("blocks", 480, 360, 70 + i, (3, 12, 40)) for i in range(13)]
+    L = np.stack([p[0] for p in pairs]); R = np.stack([p[1] for p in pairs])
+    gL, gR = orbhip.ORBextractor(*prm), orbhip.ORBextractor(*prm)
+    ref = []
+    for l, r in pairs:
+        kl, dl = gL(l, fetch_pyramid=False)
+        kr, dr = gR(r, fetch_pyramid=False)
+        u, d, n = orbhip.ComputeStereoMatches(gL, gR, kl, dl, kr, dr, BF / FX, BF)
+        ref.append((kl, dl, kr, dr, u, d, n))
+    assert sum(r[6] for r in ref) > 13 * 40
+
+    def check(res):
+        assert len(res) == len(ref)
+        for i, (a, b) in enumerate(zip(res, ref)):
+            for x, y in zip(a[:4], b[:4]):
+                assert np.array_equal(x, y), i
+            assert np.array_equal(a[4].view(np.uint32), b[4].view(np.uint32)), i
+            assert np.array_equal(a[5].view(np.uint32), b[5].view(np.uint32)), i
+            assert a[6] == b[6], i
+
+    hL, hR = _with_env({"ORBHIP_HOST_CHUNK": "3"}, lambda: (orbhip.ORBextractor(*prm), orbhip.ORBextractor(*prm)))
+    check(orbhip.extract_stereo_batch(hL, hR, L, R, BF / FX, BF))
+    Lp, Rp = torch.from_numpy(L).pin_memory().numpy(), torch.from_numpy(R).pin_memory().numpy()
+    check(orbhip.extract_stereo_batch(hL, hR, Lp, Rp, BF / FX, BF))
+    check(orbhip.extract_stereo_batch(hL, hR, L[:9], R[:9], BF / FX, BF) + ref[9:])   # same handles, fewer pairs
+    # the last chunk (pairs 6, 7, 8 of the nine) left its pyramids behind: a separate matching call reads its first pair's
+    kl, dl, kr, dr = ref[6][:4]
+    u, d, n = orbhip.ComputeStereoMatches(hL, hR, kl, dl, kr, dr, BF / FX, BF)
+    assert n == ref[6][6] and np.array_equal(u.view(np.uint32), ref[6][4].view(np.uint32))
+    oL, oR = _with_env({"ORBHIP_HOST_PIPELINE": "0"}, lambda: (orbhip.ORBextractor(*prm), orbhip.ORBextractor(*prm)))
+    check(orbhip.extract_stereo_batch(oL, oR, L, R, BF / FX, BF))
 
 
 def test_graph_replay_restores_its_level0_view():

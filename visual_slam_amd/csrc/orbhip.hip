@@ -726,6 +726,23 @@ int check_status(orbhip_extractor* e) {
     return ORBHIP_OK;
 }
 
+// A thread that is joined when its owner goes out of scope (every return path of the pipelines below).
+struct HelperThread {
+    std::thread t;
+    void join() { if (t.joinable()) t.join(); }
+    ~HelperThread() { join(); }
+};
+
+// body(first, n) over [first, first + count) in up to `threads` slices of at least 8 items, a thread each (the caller's included).
+template <typename F>
+void run_sliced(int threads, int first, int count, F&& body) {
+    const int nt = std::max(1, std::min(threads, count / 8));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back([&body, first, count, t, nt] { body(first + count * t / nt, count * (t + 1) / nt - count * t / nt); });
+    body(first, count / nt);
+    for (std::thread& t : th) t.join();
+}
+
 void collect_timing(orbhip_extractor* e) {
     // kc_ms: the spans of a class added up; kc_busy_ms: the time during which at least one span of the class was open
     // (launches of one class run side by side on two streams when FAST follows the resize chain level by level)
@@ -1112,7 +1129,9 @@ static int extract_host_pipelined(orbhip_extractor* e, const uint8_t* imgs, int 
     chunk = std::max(1, std::min(chunk, budget));
     const int nchunks = (nframes + chunk - 1) / chunk;
     const int nb = std::min(e->host_lanes, nchunks);           // input buffers: chunks in flight
-    const bool pinned = host_pointer_is_pinned(imgs);
+    // page-locked images in the staging layout are copied from where they lie; any other layout is packed by the host
+    // threads first (a strided copy from host memory runs row by row: 1241-byte rows move at a hundredth of the rate)
+    const bool pinned = row_stride == dev_row && frame_stride == dev_frame && host_pointer_is_pinned(imgs);
     HostStage hs;
     int rc = host_staging(e, (size_t)nb * chunk * dev_frame, !pinned, nframes, cap, &hs);
     if (rc) return rc;
@@ -1143,14 +1162,21 @@ static int extract_host_pipelined(orbhip_extractor* e, const uint8_t* imgs, int 
         thost.assign((size_t)nchunks * 4, 0.0);
         (void)hipEventRecord(tev[(size_t)nchunks * 4], s_up);
     }
+    // (the results of a chunk are handed to the caller's arrays by helper threads while this one packs the next chunk:
+    // with small images, many keypoints per image byte, the host's copying is what bounds the call)
+    HelperThread helper;
     for (int k = 0; k < nchunks + nb; k++) {
         const int b = k % nb;
+        helper.join();
         if (k >= nb) {                                         // chunk k - nb used this buffer: its results are down
             if (hipEventSynchronize(e->ev_down[b]) != hipSuccess) { e->err = "a chunk of the batch failed on the device"; return fail(ORBHIP_ERR_HIP); }
             if (trace) thost[(size_t)(k - nb) * 4 + 2] = now_ms();
             const int j0 = (k - nb) * chunk;
-            unpack_frames(hs, j0, std::min(chunk, nframes - j0), cap, kp, desc, counts);
-            if (trace) thost[(size_t)(k - nb) * 4 + 3] = now_ms();
+            double* const t_done = trace ? &thost[(size_t)(k - nb) * 4 + 3] : nullptr;
+            helper.t = std::thread([&, j0, t_done](int count) {
+                run_sliced(e->pack_threads, j0, count, [&](int first, int n) { unpack_frames(hs, first, n, cap, kp, desc, counts); });
+                if (t_done) *t_done = now_ms();
+            }, std::min(chunk, nframes - j0));
         }
         if (k >= nchunks) continue;
         if (trace) thost[(size_t)k * 4] = now_ms();
@@ -1161,14 +1187,7 @@ static int extract_host_pipelined(orbhip_extractor* e, const uint8_t* imgs, int 
         if (!pinned) pack_frames(src, row_stride, frame_stride, e->h_in + (size_t)b * chunk * dev_frame, dev_row, height, width_bytes, n, e->pack_threads);
         if (trace) (void)hipEventRecord(tev[(size_t)k * 4], s_up);
         if (pinned) {
-            if (row_stride == dev_row && frame_stride == dev_frame)
-                st = hipMemcpyAsync(d_in, src, (size_t)n * dev_frame - (dev_row - width_bytes), hipMemcpyHostToDevice, s_up);
-            else if (frame_stride == row_stride * (size_t)height)
-                st = hipMemcpy2DAsync(d_in, dev_row, src, row_stride, width_bytes, (size_t)height * n, hipMemcpyHostToDevice, s_up);
-            else
-                for (int f = 0; f < n && st == hipSuccess; f++)
-                    st = hipMemcpy2DAsync(d_in + (size_t)f * dev_frame, dev_row, src + (size_t)f * frame_stride, row_stride, width_bytes,
-                                          (size_t)height, hipMemcpyHostToDevice, s_up);
+            st = hipMemcpyAsync(d_in, src, (size_t)n * dev_frame - (dev_row - width_bytes), hipMemcpyHostToDevice, s_up);
         } else {
             st = hipMemcpyAsync(d_in, e->h_in + (size_t)b * chunk * dev_frame, (size_t)n * dev_frame, hipMemcpyHostToDevice, s_up);
         }
@@ -1190,6 +1209,7 @@ static int extract_host_pipelined(orbhip_extractor* e, const uint8_t* imgs, int 
         if (st != hipSuccess) { e->err = std::string("copy of a chunk's results: ") + hipGetErrorString(st); return fail(ORBHIP_ERR_HIP); }
         if (trace) thost[(size_t)k * 4 + 1] = now_ms();
     }
+    helper.join();
     if (trace) {
         (void)hipDeviceSynchronize();
         std::fprintf(stderr, "orbhip host batch: %d frames, %d chunks of %d, %d in flight, %s input, %.3f ms\n", nframes, nchunks, chunk, nb,
@@ -1230,15 +1250,16 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
     const size_t kp_bytes = hs.kp_bytes, desc_bytes = hs.desc_bytes;
     // Images up, in row bands of about half a megabyte: a band travels while the next one is packed into the
     // page-locked buffer (one thread packs a camera frame in about the time its copy takes; a 2-D copy from
-    // pageable memory would go row by row). Images that lie in page-locked memory are copied from there.
+    // host memory would go row by row). Images that lie in page-locked memory with the staging buffer's row pitch are
+    // copied from there.
     if (e->last_stream && e->last_stream != e->stream) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_busy, 0));
     e->last_stream = e->stream;
     {
         const size_t width_bytes = (size_t)width * channels;
-        if (host_pointer_is_pinned(imgs)) {
+        if (row_stride == dev_row && host_pointer_is_pinned(imgs)) {   // (rows of another pitch are packed: a strided copy runs row by row)
             for (int f = 0; f < nframes; f++)
-                HIP_TRY(e, hipMemcpy2DAsync(e->d_in + (size_t)f * dev_frame, dev_row, imgs + (size_t)f * frame_stride, row_stride, width_bytes,
-                                            (size_t)height, hipMemcpyHostToDevice, e->stream));
+                HIP_TRY(e, hipMemcpyAsync(e->d_in + (size_t)f * dev_frame, imgs + (size_t)f * frame_stride, dev_frame - (dev_row - width_bytes),
+                                          hipMemcpyHostToDevice, e->stream));
         } else {
             const size_t rows = (size_t)nframes * (size_t)height;
             const size_t band = std::max<size_t>(16, ((size_t)512 << 10) / dev_row);
@@ -1854,6 +1875,139 @@ int orbhip_stereo_match(orbhip_extractor* left, orbhip_extractor* right,
     return ORBHIP_OK;
 }
 
+// mvuRight, mvDepth and the match count per pair of a host stereo batch: device arrays and their pinned copy, owned
+// by the left instance ([uright][depth] of npairs * cap floats each, then npairs counts).
+static int stereo_host_outputs(orbhip_extractor* e, int npairs, int cap, size_t* fl_bytes, size_t* st_bytes) {
+    *fl_bytes = (size_t)npairs * cap * sizeof(float);
+    *st_bytes = 2 * *fl_bytes + (((size_t)npairs * sizeof(int) + 15) & ~(size_t)15);
+    if (*st_bytes > e->st_host_bytes) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        dfree(e->d_st_host);
+        if (e->h_st_host) (void)hipHostFree(e->h_st_host);
+        e->h_st_host = nullptr; e->st_host_bytes = 0;
+        HIP_TRY(e, hipMalloc(&e->d_st_host, *st_bytes));
+        HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_st_host), *st_bytes, hipHostMallocDefault));
+        e->st_host_bytes = *st_bytes;
+    }
+    return ORBHIP_OK;
+}
+
+// A batch of stereo pairs in host memory as the same pipeline of chunks as extract_host_pipelined (one stream per
+// stage: copies up, kernels, copies down; the left instance's streams and events carry it): a chunk is so many pairs
+// that its two sides together are about 64 MB of images; both sides of a chunk are extracted and matched on the device
+// (orbhip_extract_stereo_batch_device) while the neighbouring chunks travel.
+static int extract_stereo_host_pipelined(orbhip_extractor* left, orbhip_extractor* right, const uint8_t* imgs_l, const uint8_t* imgs_r,
+                                         int npairs, int width, int height, size_t row_stride, size_t frame_stride,
+                                         orbhip_keypoint* kp_l, uint8_t* desc_l, int* cnt_l, orbhip_keypoint* kp_r, uint8_t* desc_r,
+                                         int* cnt_r, int cap, float mb, float mbf, float* uright, float* depth, int* nmatch) {
+    orbhip_extractor* e = left;
+    orbhip_extractor* const sides[2] = {left, right};
+    const uint8_t* const imgs[2] = {imgs_l, imgs_r};
+    const size_t width_bytes = (size_t)width;
+    const size_t dev_row = (width_bytes + 15) & ~(size_t)15, dev_frame = dev_row * height;
+    const int budget = std::min(pass_budget(left, width, height), pass_budget(right, width, height));
+    int chunk = e->host_chunk > 0 ? e->host_chunk : (int)std::max<size_t>(4, ((size_t)32 << 20) / dev_frame);
+    chunk = std::min(chunk, (npairs + 3) / 4);
+    chunk = std::max(1, std::min(chunk, budget));
+    const int nchunks = (npairs + chunk - 1) / chunk;
+    const int nb = std::min(e->host_lanes, nchunks);
+    const bool staged_layout = row_stride == dev_row && frame_stride == dev_frame;   // (see extract_host_pipelined)
+    const bool pinned[2] = {staged_layout && host_pointer_is_pinned(imgs_l), staged_layout && host_pointer_is_pinned(imgs_r)};
+    HostStage hst[2];
+    for (int k = 0; k < 2; k++) {
+        const int rc = host_staging(sides[k], (size_t)nb * chunk * dev_frame, !pinned[k], npairs, cap, &hst[k]);
+        if (rc) { if (k) e->err = right->err; return rc; }
+    }
+    size_t fl_bytes = 0, st_bytes = 0;
+    int rc = stereo_host_outputs(e, npairs, cap, &fl_bytes, &st_bytes);
+    if (rc) return rc;
+    float* const d_ur = reinterpret_cast<float*>(e->d_st_host);
+    float* const d_dep = reinterpret_cast<float*>(e->d_st_host + fl_bytes);
+    int* const d_nm = reinterpret_cast<int*>(e->d_st_host + 2 * fl_bytes);
+    float* const h_ur = reinterpret_cast<float*>(e->h_st_host);
+    float* const h_dep = reinterpret_cast<float*>(e->h_st_host + fl_bytes);
+    int* const h_nm = reinterpret_cast<int*>(e->h_st_host + 2 * fl_bytes);
+    // earlier work of the two handles (on whatever stream) is over before their buffers are touched
+    for (orbhip_extractor* x : sides)
+        if (x->last_stream) HIP_TRY(e, hipEventSynchronize(x->ev_busy));
+    auto fail = [&](int code) { (void)hipDeviceSynchronize(); return code; };   // nothing of this call stays in flight
+    const hipStream_t s_up = e->ws[0].stream, s_run = e->stream, s_down = e->ws[1].stream;
+    auto unpack = [&](int j0, int n) {
+        unpack_frames(hst[0], j0, n, cap, kp_l, desc_l, cnt_l);
+        unpack_frames(hst[1], j0, n, cap, kp_r, desc_r, cnt_r);
+        for (int f = j0; f < j0 + n; f++) {
+            const int m = std::min(cnt_l[f], cap);
+            if (m <= 0) continue;
+            std::memcpy(uright + (size_t)f * cap, h_ur + (size_t)f * cap, (size_t)m * sizeof(float));
+            std::memcpy(depth + (size_t)f * cap, h_dep + (size_t)f * cap, (size_t)m * sizeof(float));
+        }
+        if (nmatch) std::memcpy(nmatch + j0, h_nm + j0, (size_t)n * sizeof(int));
+    };
+    // (the results of a chunk are handed to the caller's arrays by a helper thread while this one packs the next chunk:
+    // with pageable images the host's copying, not the transfer, is what bounds this call)
+    HelperThread helper;
+    for (int k = 0; k < nchunks + nb; k++) {
+        const int b = k % nb;
+        helper.join();
+        if (k >= nb) {                                         // chunk k - nb used this buffer: its results are down
+            if (hipEventSynchronize(e->ev_down[b]) != hipSuccess) { e->err = "a chunk of the batch failed on the device"; return fail(ORBHIP_ERR_HIP); }
+            const int j0 = (k - nb) * chunk;
+            helper.t = std::thread([&unpack, e](int first, int count) { run_sliced(e->pack_threads, first, count, unpack); },
+                                   j0, std::min(chunk, npairs - j0));
+        }
+        if (k >= nchunks) continue;
+        const int f0 = k * chunk, n = std::min(chunk, npairs - f0);
+        hipError_t st = hipSuccess;
+        uint8_t* d_in[2];
+        for (int side = 0; side < 2 && st == hipSuccess; side++) {
+            orbhip_extractor* x = sides[side];
+            d_in[side] = x->d_in + (size_t)b * chunk * dev_frame;
+            const uint8_t* src = imgs[side] + (size_t)f0 * frame_stride;
+            if (!pinned[side]) {
+                uint8_t* h_in = x->h_in + (size_t)b * chunk * dev_frame;
+                pack_frames(src, row_stride, frame_stride, h_in, dev_row, height, width_bytes, n, e->pack_threads);
+                st = hipMemcpyAsync(d_in[side], h_in, (size_t)n * dev_frame, hipMemcpyHostToDevice, s_up);
+            } else {
+                st = hipMemcpyAsync(d_in[side], src, (size_t)n * dev_frame - (dev_row - width_bytes), hipMemcpyHostToDevice, s_up);
+            }
+        }
+        if (st == hipSuccess) st = hipEventRecord(e->ev_up[b], s_up);
+        if (st == hipSuccess) st = hipStreamWaitEvent(s_run, e->ev_up[b], 0);
+        if (st != hipSuccess) { e->err = std::string("copy of a chunk to the device: ") + hipGetErrorString(st); return fail(ORBHIP_ERR_HIP); }
+        const size_t o = (size_t)f0 * cap;
+        rc = orbhip_extract_stereo_batch_device(left, right, d_in[0], d_in[1], n, width, height, dev_row, dev_frame,
+                                                reinterpret_cast<orbhip_keypoint*>(left->d_out_kp) + o, left->d_out_desc + o * 32, left->d_out_cnt + f0,
+                                                reinterpret_cast<orbhip_keypoint*>(right->d_out_kp) + o, right->d_out_desc + o * 32, right->d_out_cnt + f0,
+                                                cap, mb, mbf, d_ur + o, d_dep + o, d_nm + f0, s_run);
+        if (rc) return fail(rc);
+        st = hipEventRecord(e->ev_run[b], s_run);
+        if (st == hipSuccess) st = hipStreamWaitEvent(s_down, e->ev_run[b], 0);
+        for (int side = 0; side < 2 && st == hipSuccess; side++) {
+            orbhip_extractor* x = sides[side];
+            const HostStage& h = hst[side];
+            st = hipMemcpyAsync(h.h_cnt + (size_t)f0 * sizeof(int), x->d_out_cnt + f0, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s_down);
+            if (st == hipSuccess) st = hipMemcpyAsync(h.h_kp + o * sizeof(orbhip_keypoint), x->d_out_kp + o * 7, (size_t)n * cap * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, s_down);
+            if (st == hipSuccess) st = hipMemcpyAsync(h.h_desc + o * 32, x->d_out_desc + o * 32, (size_t)n * cap * 32, hipMemcpyDeviceToHost, s_down);
+        }
+        if (st == hipSuccess) st = hipMemcpyAsync(h_ur + o, d_ur + o, (size_t)n * cap * sizeof(float), hipMemcpyDeviceToHost, s_down);
+        if (st == hipSuccess) st = hipMemcpyAsync(h_dep + o, d_dep + o, (size_t)n * cap * sizeof(float), hipMemcpyDeviceToHost, s_down);
+        if (st == hipSuccess) st = hipMemcpyAsync(h_nm + f0, d_nm + f0, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s_down);
+        if (st == hipSuccess) st = hipEventRecord(e->ev_down[b], s_down);
+        if (st != hipSuccess) { e->err = std::string("copy of a chunk's results: ") + hipGetErrorString(st); return fail(ORBHIP_ERR_HIP); }
+    }
+    helper.join();
+    // every chunk's results are down, so the kernels are over: the status words of the whole batch
+    for (int side = 0; side < 2; side++)
+        HIP_TRY(e, hipMemcpyAsync(hst[side].h_status, sides[side]->d_status, sizeof(int), hipMemcpyDeviceToHost, s_run));
+    HIP_TRY(e, hipStreamSynchronize(s_run));
+    collect_timing(left); collect_timing(right);
+    rc = host_status(left, hst[0], s_run);
+    if (rc) return rc;
+    rc = host_status(right, hst[1], s_run);
+    if (rc) { e->err = right->err; return rc; }
+    return ORBHIP_OK;
+}
+
 int orbhip_extract_stereo_batch(orbhip_extractor* left, orbhip_extractor* right, const uint8_t* imgs_l, const uint8_t* imgs_r,
                                 int npairs, int width, int height, size_t row_stride, size_t frame_stride,
                                 orbhip_keypoint* kp_l, uint8_t* desc_l, int* cnt_l, orbhip_keypoint* kp_r, uint8_t* desc_r, int* cnt_r,
@@ -1866,24 +2020,18 @@ int orbhip_extract_stereo_batch(orbhip_extractor* left, orbhip_extractor* right,
     orbhip_extractor* e = left;
     if (left->device != right->device) { e->err = "left and right instances live on different devices"; return ORBHIP_ERR_ARG; }
     DEVICE_SCOPE(e);
+    if (npairs >= kPipelineMinFrames && e->host_pipeline)
+        return extract_stereo_host_pipelined(left, right, imgs_l, imgs_r, npairs, width, height, row_stride, frame_stride,
+                                             kp_l, desc_l, cnt_l, kp_r, desc_r, cnt_r, cap, mb, mbf, uright, depth, nmatch);
     const size_t dev_row = ((size_t)width + 15) & ~(size_t)15, dev_frame = dev_row * height;
     HostStage hl, hr;
     int rc = host_staging(left, dev_frame * npairs, true, npairs, cap, &hl);
     if (rc) return rc;
     rc = host_staging(right, dev_frame * npairs, true, npairs, cap, &hr);
     if (rc) { e->err = right->err; return rc; }
-    // mvuRight, mvDepth and the match count per pair: device arrays and their pinned copy, owned by the left instance
-    const size_t fl_bytes = (size_t)npairs * cap * sizeof(float), nm_bytes = ((size_t)npairs * sizeof(int) + 15) & ~(size_t)15;
-    const size_t st_bytes = 2 * fl_bytes + nm_bytes;
-    if (st_bytes > e->st_host_bytes) {
-        HIP_TRY(e, hipDeviceSynchronize());
-        dfree(e->d_st_host);
-        if (e->h_st_host) (void)hipHostFree(e->h_st_host);
-        e->h_st_host = nullptr; e->st_host_bytes = 0;
-        HIP_TRY(e, hipMalloc(&e->d_st_host, st_bytes));
-        HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_st_host), st_bytes, hipHostMallocDefault));
-        e->st_host_bytes = st_bytes;
-    }
+    size_t fl_bytes = 0, st_bytes = 0;
+    rc = stereo_host_outputs(e, npairs, cap, &fl_bytes, &st_bytes);
+    if (rc) return rc;
     float* d_ur = reinterpret_cast<float*>(e->d_st_host);
     float* d_dep = reinterpret_cast<float*>(e->d_st_host + fl_bytes);
     int* d_nm = reinterpret_cast<int*>(e->d_st_host + 2 * fl_bytes);
