@@ -349,8 +349,7 @@ def main():
         # leads with (it says what the kernel achieves, and it is what a kernel trace of ORBHIP_OVERLAP=0 shows); the
         # figures as run move to "as_run".
         ov = os.environ.get("ORBHIP_OVERLAP", "1")
-        overlap_on = ov == "2" or (ov != "0" and (frames_per_launch * w * h >= 5.0e7 if not args.stereo else
-                                                  (w * h >= 4.0e5 and frames_per_launch * w * h >= 2.0e8)))   # the library's own rule
+        overlap_on = ov == "2" or (ov != "0" and frames_per_launch * w * h >= (1.0e8 if args.stereo else 5.0e7))   # the library's own rule
         roofline["fast_beside_resize"] = bool(overlap_on)
         if (lanes > 1 or overlap_on) and not args.skip_alone and not args.stereo:   # (the stereo step has no one-at-a-time twin here)
             saved = {k: os.environ.get(k) for k in ("ORBHIP_LANES", "ORBHIP_OVERLAP")}

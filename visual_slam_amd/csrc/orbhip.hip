@@ -70,8 +70,7 @@ const int kLanes = 4;
 const int kQtSmallQuota = 300;
 const int kQtLatencyGroups = 256;   // (frames x levels) up to this: a pass that cannot fill the chip
 const double kOverlapMinPixels = 5.0e7;   // passes of at least this many input pixels run FAST on a second stream beside the resize chain;
-const double kOverlapMinPixelsPair = 2.0e8, kOverlapMinImagePair = 4.0e5;   // the two sides of a stereo batch, one after the other on one
-                                                                            // stream: larger passes of images of at least this size only
+const double kOverlapMinPixelsPair = 1.0e8;   // the two sides of a stereo batch already run beside each other: larger passes only
 const int kMinLaneFrames = 16;     // batches below twice this run as one pass on the caller's stream
 const int kPipelineMinFrames = 8;  // host batches from this size on are cut into chunks that overlap copy, extraction and copy back
 
@@ -141,6 +140,7 @@ struct orbhip_extractor {
     int fast_pack = 1;             // ORBHIP_FAST_PACK=0: every tile of k_fast is a plain one (no bands in the last tile column)
     int inplace_l0 = 1;            // ORBHIP_INPLACE_LEVEL0=0: always copy gray input into the level-0 plane
     std::vector<int> l1_base;      // per 4-pixel group of level 1's plane: 4-aligned first source column of its taps
+    int stereo_fork = 1;           // ORBHIP_STEREO_FORK=0: the right side of a stereo pass runs behind the left one on the same stream
     bool in_pair = false;          // set around the passes of a stereo batch call (the overlap rule differs)
     int overlap = 1;               // ORBHIP_OVERLAP=0: FAST of level 0 never runs beside the resize chain on aux_stream; 2: for passes of any size
     hipStream_t aux_stream = nullptr;
@@ -607,10 +607,10 @@ int run_pass(orbhip_extractor* e, Workspace& W, hipStream_t s, const uint8_t* d_
     // the chain, level by level (below). Measured per pass against one stream: 1080p x 1024 frames +4 to +6 %, x 64 +4 %,
     // x 32 +2 %, x 16 +1 %, x 8 -2 %; 1241 x 376 x 1024 +6 %, x 32 -5 %; VGA x 1024 +2 to +3 %, x 256 +2 %, x 64 -3 %, x 16 -10 %:
     // the fork and join cost more than a short chain can hide, hence the smallest pass. The two sides of a stereo batch
-    // (752 x 480 x 512 pairs -2 %, x 64 pairs -12 %, 1080p x 256 pairs +0.5 %) keep the rule of large passes of large images.
+    // run beside each other on two streams already; four streams pay from larger passes on (per side: 752 x 480 x 512 +3 %,
+    // 1241 x 376 x 256 +4 %, 1080p x 64 +3 %; 752 x 480 x 64 -4 %).
     const double px0 = (double)P.lv[0].w * P.lv[0].h;
-    const bool large = e->in_pair ? px0 >= kOverlapMinImagePair && (double)frames * px0 >= kOverlapMinPixelsPair
-                                  : (double)frames * px0 >= kOverlapMinPixels;
+    const bool large = (double)frames * px0 >= (e->in_pair ? kOverlapMinPixelsPair : kOverlapMinPixels);
     const bool beside = e->overlap && nl > 1 && (e->overlap > 1 || large);
     // With `beside` the plain FAST tiles run on the second stream, level by level as the chain on the main stream
     // delivers the levels: the first `ksplit` levels as launches of their own, the rest in one launch behind the
@@ -857,6 +857,7 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
     if (const char* v = std::getenv("ORBHIP_DEBUG_SYNC")) e->debug_sync = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_LANES")) e->max_lanes = std::min(kLanes, std::max(1, std::atoi(v)));
     if (const char* v = std::getenv("ORBHIP_OVERLAP")) e->overlap = std::min(2, std::max(0, std::atoi(v)));
+    if (const char* v = std::getenv("ORBHIP_STEREO_FORK")) e->stereo_fork = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_FAST_SPLIT")) e->fast_split_levels = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("ORBHIP_INPLACE_LEVEL0")) e->inplace_l0 = std::atoi(v) != 0;
     if (const char* v = std::getenv("ORBHIP_FAST_PACK")) e->fast_pack = std::atoi(v) != 0;
@@ -1812,14 +1813,25 @@ int orbhip_extract_stereo_batch_device(orbhip_extractor* left, orbhip_extractor*
         PairScope(orbhip_extractor* l, orbhip_extractor* r) : a(l), b(r) { a->in_pair = b->in_pair = true; }
         ~PairScope() { a->in_pair = b->in_pair = false; }
     } pair_scope(left, right);
+    // The two sides of a pass are independent until they are matched: the right one runs on the right instance's own
+    // stream, forked from and joined into `s` (ORBHIP_STEREO_FORK=0: one after the other on `s`).
+    const hipStream_t sr = (e->stereo_fork && right->stream != s) ? right->stream : s;
     for (int f0 = 0; f0 < nframes; f0 += chunk) {
         const int n = std::min(chunk, nframes - f0);
+        if (sr != s) {                                         // (behind the matching of the previous pass, which reads the right pyramids)
+            HIP_TRY(e, hipEventRecord(e->ev_fork, s));
+            HIP_TRY(e, hipStreamWaitEvent(sr, e->ev_fork, 0));
+        }
         rc = run_pass(left, left->ws[0], s, d_imgs_l + (size_t)f0 * frame_stride, n, row_stride, frame_stride, (size_t)width, 1, 0,
                       reinterpret_cast<float*>(d_kp_l), d_desc_l, d_cnt_l, cap, f0);
         if (rc) return rc;
-        rc = run_pass(right, right->ws[0], s, d_imgs_r + (size_t)f0 * frame_stride, n, row_stride, frame_stride, (size_t)width, 1, 0,
+        rc = run_pass(right, right->ws[0], sr, d_imgs_r + (size_t)f0 * frame_stride, n, row_stride, frame_stride, (size_t)width, 1, 0,
                       reinterpret_cast<float*>(d_kp_r), d_desc_r, d_cnt_r, cap, f0);
         if (rc) { e->err = right->err; return rc; }
+        if (sr != s) {
+            HIP_TRY(e, hipEventRecord(right->ws[0].done, sr));
+            HIP_TRY(e, hipStreamWaitEvent(s, right->ws[0].done, 0));
+        }
         const size_t o = (size_t)f0 * cap;
         rc = stereo_batch_launch(left, right, n, d_kp_l + o, d_desc_l + o * 32, d_cnt_l + f0, d_kp_r + o, d_desc_r + o * 32, d_cnt_r + f0,
                                  cap, mb, mbf, d_uright + o, d_depth + o, d_nmatch ? d_nmatch + f0 : nullptr, s,
