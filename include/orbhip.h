@@ -55,7 +55,7 @@ typedef struct orbhip_params {
     int min_th_fast;      /* ORBextractor.minThFAST  */
     int device;           /* HIP device ordinal */
     int blur_variant;     /* ORBHIP_BLUR_* */
-    int max_batch;        /* frames processed per internal pass of the batch entry points (0 = default 512; also capped by a ~24 GB workspace limit) */
+    int max_batch;        /* frames processed per internal pass of the batch entry points (0 = default: 512, more of images smaller than 1920 x 1080, as many pixels per pass; also capped by a ~24 GB workspace limit) */
 } orbhip_params;
 
 typedef struct orbhip_extractor orbhip_extractor;

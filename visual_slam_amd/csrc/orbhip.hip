@@ -786,7 +786,7 @@ int orbhip_create(const orbhip_params* p, orbhip_extractor** out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || p->device < 0 || p->device >= ndev) return ORBHIP_ERR_NO_DEVICE;
     orbhip_extractor* e = new orbhip_extractor;
     e->prm = *p;
-    if (e->prm.max_batch < 1) e->prm.max_batch = 512;
+    if (e->prm.max_batch < 1) e->prm.max_batch = 0;            // by image size: see pass_budget
     e->device = p->device;
     const int nl = p->nlevels;
     // src/ORBextractor.cc:412-431 (scaleFactor is a double member initialised from the float argument)
@@ -917,7 +917,11 @@ static int pass_budget(const orbhip_extractor* e, int width, int height) {
     const unsigned long long groups = ((unsigned long long)orbhip_max_keypoints(e) + 3) / 4;
     const int grid_limit = (int)std::min<unsigned long long>(1u << 20, 8ull * (((1ull << 26) - 1) / (groups * groups)));
     // (the frame index is the y or z coordinate of several grids: at most 65535)
-    return std::max(1, std::min(std::min(std::min(e->prm.max_batch, ws_limit), std::max(grid_limit, 8)), 65535));
+    // Default pass: 512 frames, more of small images (as many pixels as 512 frames of 1080p: the dozen dependent launches
+    // of a pass cost their gaps once per pass; 640 x 480: 379 / 400 / 409 k frames/s with passes of 512 / 1024 / 2048).
+    const int max_batch = e->prm.max_batch > 0 ? e->prm.max_batch
+                                               : std::max(512, (int)(512.0 * 1920.0 * 1080.0 / ((double)width * (double)height)));
+    return std::max(1, std::min(std::min(std::min(max_batch, ws_limit), std::max(grid_limit, 8)), 65535));
 }
 
 static int extract_device_impl(orbhip_extractor* e, const uint8_t* d_imgs, int nframes, int width, int height,
