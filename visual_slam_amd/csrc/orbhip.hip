@@ -1159,7 +1159,9 @@ static int extract_host_pipelined(orbhip_extractor* e, const uint8_t* imgs, int 
     const bool trace = e->host_trace;
     const auto t_call = std::chrono::steady_clock::now();
     auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
-    std::vector<hipEvent_t> tev;
+    struct TraceEvents : std::vector<hipEvent_t> {             // destroyed on every return path
+        ~TraceEvents() { for (hipEvent_t ev : *this) if (ev) (void)hipEventDestroy(ev); }
+    } tev;
     std::vector<double> thost;
     if (trace) {
         tev.resize((size_t)nchunks * 4 + 1, nullptr);
@@ -1226,7 +1228,6 @@ static int extract_host_pipelined(orbhip_extractor* e, const uint8_t* imgs, int 
             std::fprintf(stderr, "  %3d: host [%7.3f..%7.3f | %7.3f, %7.3f]   device [%7.3f..%7.3f, %7.3f, %7.3f]\n", k, thost[(size_t)k * 4],
                          thost[(size_t)k * 4 + 1], thost[(size_t)k * 4 + 2], thost[(size_t)k * 4 + 3], d[0], d[1], d[2], d[3]);
         }
-        for (hipEvent_t ev : tev) (void)hipEventDestroy(ev);
     }
     // every chunk's results are down (the loop waited for each one's event), so the kernels are over: the status word of the whole batch
     HIP_TRY(e, hipMemcpyAsync(hs.h_status, e->d_status, sizeof(int), hipMemcpyDeviceToHost, s_run));
