@@ -194,6 +194,7 @@ struct orbhip_extractor {
     int4* d_st_rinfo = nullptr;                          // [frames][cap] row band / octave / x of the right keypoints, binned by row
     int* d_st_bins = nullptr; size_t d_st_bins_n = 0;    // [frames][nbins + 1] record range of every row bin
     uint8_t* d_st_tmp = nullptr; size_t d_st_tmp_bytes = 0;   // staging of the host-array entry point
+    uint8_t* h_st_tmp = nullptr; size_t h_st_tmp_bytes = 0;   // its page-locked twin
     uint8_t* d_match_spill = nullptr; size_t d_match_spill_bytes = 0;   // matcher state of frames too large for LDS
     uint8_t* d_st_host = nullptr; uint8_t* h_st_host = nullptr; size_t st_host_bytes = 0;   // mvuRight / mvDepth / match counts of the host stereo batch call
     // timing
@@ -885,6 +886,7 @@ int orbhip_destroy(orbhip_extractor* e) {
     dfree(e->d_st_sad); dfree(e->d_st_rinfo); dfree(e->d_st_bins); dfree(e->d_st_tmp); dfree(e->d_match_spill);
     dfree(e->d_map_x); dfree(e->d_map_y); dfree(e->d_st_host);
     if (e->h_st_host) (void)hipHostFree(e->h_st_host);
+    if (e->h_st_tmp) (void)hipHostFree(e->h_st_tmp);
     if (e->h_in) (void)hipHostFree(e->h_in);
     if (e->h_out) (void)hipHostFree(e->h_out);
     if (e->h_pyr) (void)hipHostFree(e->h_pyr);
@@ -1238,15 +1240,27 @@ static int extract_host_pipelined(orbhip_extractor* e, const uint8_t* imgs, int 
     return host_status(e, hs, s_run);
 }
 
+// The end of a host call that was enqueued with `defer`: waits for the handle's stream and hands the results over.
+static int extract_host_finish(orbhip_extractor* e, const HostStage& hs, int nframes, int cap, orbhip_keypoint* kp, uint8_t* desc, int* counts) {
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    collect_timing(e);
+    const int rc = host_status(e, hs, e->stream);
+    if (rc) return rc;
+    unpack_frames(hs, 0, nframes, cap, kp, desc, counts);
+    return ORBHIP_OK;
+}
+
+// defer: the call returns with everything enqueued on the handle's stream (copies down included) and leaves the wait
+// and the hand-over to extract_host_finish (small batches only: the chunk pipeline waits by itself).
 static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nframes, int width, int height,
                              size_t row_stride, size_t frame_stride, int channels, int rgb, orbhip_keypoint* kp,
-                             uint8_t* desc, int* counts, int cap) {
+                             uint8_t* desc, int* counts, int cap, HostStage* defer = nullptr) {
     if (!e || !kp || !desc || !counts || cap < 1 || nframes < 0 || (channels != 1 && channels != 3 && channels != 4))
         return ORBHIP_ERR_ARG;
     if (!imgs || width <= 0 || height <= 0 || nframes == 0) return ORBHIP_ERR_EMPTY;
     if (row_stride < (size_t)width * channels) return ORBHIP_ERR_ARG;
     DEVICE_SCOPE(e);
-    if (nframes >= kPipelineMinFrames && e->host_pipeline)
+    if (nframes >= kPipelineMinFrames && e->host_pipeline && !defer)
         return extract_host_pipelined(e, imgs, nframes, width, height, row_stride, frame_stride, channels, rgb, kp, desc, counts, cap);
     const size_t dev_row = ((size_t)width * channels + 15) & ~(size_t)15, dev_frame = dev_row * height;
     const size_t need = dev_frame * nframes;
@@ -1341,12 +1355,8 @@ static int extract_host_impl(orbhip_extractor* e, const uint8_t* imgs, int nfram
         HIP_TRY(e, hipMemcpyAsync(h_desc, e->d_out_desc, desc_bytes, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipMemcpyAsync(hs.h_status, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     }
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    collect_timing(e);
-    rc = host_status(e, hs, e->stream);
-    if (rc) return rc;
-    unpack_frames(hs, 0, nframes, cap, kp, desc, counts);
-    return ORBHIP_OK;
+    if (defer) { *defer = hs; return ORBHIP_OK; }
+    return extract_host_finish(e, hs, nframes, cap, kp, desc, counts);
 }
 
 int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int nframes, int width, int height,
@@ -1858,37 +1868,50 @@ int orbhip_stereo_match(orbhip_extractor* left, orbhip_extractor* right,
     DEVICE_SCOPE(e);
     const int cap = std::max(std::max(n_l, n_r), 1);
     const size_t kpb = (size_t)cap * sizeof(orbhip_keypoint), db = (size_t)cap * 32, fb = (size_t)cap * sizeof(float);
-    const size_t need = 2 * kpb + 2 * db + 2 * fb + 64;
-    if (need > e->d_st_tmp_bytes) {
+    // One staging block on the device and its page-locked twin: [counts, 64 bytes][mvuRight][mvDepth] (what comes back,
+    // one copy) then [left keypoints][right keypoints][left descriptors][right descriptors] (what goes up with the
+    // counts, one copy of the whole block); one wait at the end. (A front end calls this once per frame.)
+    const size_t out_bytes = 64 + 2 * fb, need = out_bytes + 2 * kpb + 2 * db;
+    if (need > e->d_st_tmp_bytes || need > e->h_st_tmp_bytes) {
         HIP_TRY(e, hipDeviceSynchronize());
         dfree(e->d_st_tmp);
+        e->d_st_tmp_bytes = 0;
+        if (e->h_st_tmp) (void)hipHostFree(e->h_st_tmp);
+        e->h_st_tmp = nullptr; e->h_st_tmp_bytes = 0;
         HIP_TRY(e, hipMalloc(&e->d_st_tmp, need));
         e->d_st_tmp_bytes = need;
+        HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_st_tmp), need, hipHostMallocDefault));
+        e->h_st_tmp_bytes = need;
     }
-    uint8_t* p = e->d_st_tmp;
-    int* d_cnt = reinterpret_cast<int*>(p); p += 64;            // [0] n_l, [1] n_r, [2] matches
-    orbhip_keypoint* d_kl = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
-    orbhip_keypoint* d_kr = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
-    uint8_t* d_dl = p; p += db;
-    uint8_t* d_dr = p; p += db;
-    float* d_u = reinterpret_cast<float*>(p); p += fb;
-    float* d_d = reinterpret_cast<float*>(p);
+    uint8_t* const d = e->d_st_tmp;
+    uint8_t* const hbuf = e->h_st_tmp;
+    int* d_cnt = reinterpret_cast<int*>(d);                        // [0] n_l, [1] n_r, [2] matches
+    float* d_u = reinterpret_cast<float*>(d + 64);
+    float* d_d = reinterpret_cast<float*>(d + 64 + fb);
+    const size_t o_kl = out_bytes, o_kr = o_kl + kpb, o_dl = o_kr + kpb, o_dr = o_dl + db;
     const int cnt[3] = {n_l, n_r, 0};
-    HIP_TRY(e, hipDeviceSynchronize());                        // both extractions (two streams) are complete
-    HIP_TRY(e, hipMemcpy(d_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_kl, kp_l, (size_t)n_l * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_dl, desc_l, (size_t)n_l * 32, hipMemcpyHostToDevice));
+    std::memcpy(hbuf, cnt, sizeof(cnt));
+    std::memcpy(hbuf + o_kl, kp_l, (size_t)n_l * sizeof(orbhip_keypoint));
+    std::memcpy(hbuf + o_dl, desc_l, (size_t)n_l * 32);
     if (n_r > 0) {
-        HIP_TRY(e, hipMemcpy(d_kr, kp_r, (size_t)n_r * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
-        HIP_TRY(e, hipMemcpy(d_dr, desc_r, (size_t)n_r * 32, hipMemcpyHostToDevice));
+        std::memcpy(hbuf + o_kr, kp_r, (size_t)n_r * sizeof(orbhip_keypoint));
+        std::memcpy(hbuf + o_dr, desc_r, (size_t)n_r * 32);
     }
-    int rc = orbhip_stereo_match_batch_device(left, right, 1, d_kl, d_dl, d_cnt, d_kr, d_dr, d_cnt + 1, cap, mb, mbf,
-                                              d_u, d_d, d_cnt + 2, nullptr);
+    // the two extractions (host calls that waited for their results, possibly on other streams) are complete
+    hipStream_t s = e->stream;
+    orbhip_extractor* const sides[2] = {left, right};
+    for (orbhip_extractor* x : sides)
+        if (x->last_stream && x->last_stream != s) HIP_TRY(e, hipStreamWaitEvent(s, x->ev_busy, 0));
+    HIP_TRY(e, hipMemcpyAsync(d, hbuf, need, hipMemcpyHostToDevice, s));
+    int rc = orbhip_stereo_match_batch_device(left, right, 1, reinterpret_cast<orbhip_keypoint*>(d + o_kl), d + o_dl, d_cnt,
+                                              reinterpret_cast<orbhip_keypoint*>(d + o_kr), d + o_dr, d_cnt + 1, cap, mb, mbf,
+                                              d_u, d_d, d_cnt + 2, s);
     if (rc) return rc;
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipMemcpy(uright, d_u, (size_t)n_l * sizeof(float), hipMemcpyDeviceToHost));
-    HIP_TRY(e, hipMemcpy(depth, d_d, (size_t)n_l * sizeof(float), hipMemcpyDeviceToHost));
-    if (nmatch) HIP_TRY(e, hipMemcpy(nmatch, d_cnt + 2, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpyAsync(hbuf, d, out_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    std::memcpy(uright, hbuf + 64, (size_t)n_l * sizeof(float));
+    std::memcpy(depth, hbuf + 64 + fb, (size_t)n_l * sizeof(float));
+    if (nmatch) *nmatch = reinterpret_cast<const int*>(hbuf)[2];
     return ORBHIP_OK;
 }
 
@@ -2040,6 +2063,44 @@ int orbhip_extract_stereo_batch(orbhip_extractor* left, orbhip_extractor* right,
     if (npairs >= kPipelineMinFrames && e->host_pipeline)
         return extract_stereo_host_pipelined(left, right, imgs_l, imgs_r, npairs, width, height, row_stride, frame_stride,
                                              kp_l, desc_l, cnt_l, kp_r, desc_r, cnt_r, cap, mb, mbf, uright, depth, nmatch);
+    if (npairs == 1) {
+        // One pair per call is what a stereo front end makes per frame (src/Frame.cc:114-122: two extractions on two
+        // threads, then the matching). Each side goes through its handle's single-frame route (a replayed graph from
+        // the second call on) on its handle's own stream, nothing waits in between; the matching follows on the left
+        // stream behind the right side's kernels, and one wait per stream ends the call.
+        HostStage hl1, hr1;
+        int rc1 = extract_host_impl(left, imgs_l, 1, width, height, row_stride, frame_stride, 1, 0, kp_l, desc_l, cnt_l, cap, &hl1);
+        if (rc1) return rc1;
+        rc1 = extract_host_impl(right, imgs_r, 1, width, height, row_stride, frame_stride, 1, 0, kp_r, desc_r, cnt_r, cap, &hr1);
+        if (rc1) { e->err = right->err; (void)hipStreamSynchronize(left->stream); return rc1; }
+        auto fail1 = [&](int code) { (void)hipStreamSynchronize(left->stream); (void)hipStreamSynchronize(right->stream); return code; };
+        size_t fl1 = 0, st1 = 0;
+        rc1 = stereo_host_outputs(e, 1, cap, &fl1, &st1);
+        if (rc1) return fail1(rc1);
+        float* const d_ur1 = reinterpret_cast<float*>(e->d_st_host);
+        float* const d_dep1 = reinterpret_cast<float*>(e->d_st_host + fl1);
+        int* const d_nm1 = reinterpret_cast<int*>(e->d_st_host + 2 * fl1);
+        hipError_t hst = hipEventRecord(right->ev_order, right->stream);
+        if (hst == hipSuccess) hst = hipStreamWaitEvent(left->stream, right->ev_order, 0);
+        if (hst != hipSuccess) { e->err = std::string("stereo pair: ") + hipGetErrorString(hst); return fail1(ORBHIP_ERR_HIP); }
+        rc1 = orbhip_stereo_match_batch_device(left, right, 1, reinterpret_cast<orbhip_keypoint*>(left->d_out_kp), left->d_out_desc, left->d_out_cnt,
+                                               reinterpret_cast<orbhip_keypoint*>(right->d_out_kp), right->d_out_desc, right->d_out_cnt, cap, mb, mbf,
+                                               d_ur1, d_dep1, d_nm1, left->stream);
+        if (rc1) return fail1(rc1);
+        hst = hipMemcpyAsync(e->h_st_host, e->d_st_host, st1, hipMemcpyDeviceToHost, left->stream);
+        if (hst != hipSuccess) { e->err = std::string("stereo pair: ") + hipGetErrorString(hst); return fail1(ORBHIP_ERR_HIP); }
+        rc1 = extract_host_finish(right, hr1, 1, cap, kp_r, desc_r, cnt_r);
+        if (rc1) { e->err = right->err; (void)hipStreamSynchronize(left->stream); return rc1; }
+        rc1 = extract_host_finish(left, hl1, 1, cap, kp_l, desc_l, cnt_l);
+        if (rc1) return rc1;
+        const int m = std::min(cnt_l[0], cap);
+        if (m > 0) {
+            std::memcpy(uright, e->h_st_host, (size_t)m * sizeof(float));
+            std::memcpy(depth, e->h_st_host + fl1, (size_t)m * sizeof(float));
+        }
+        if (nmatch) nmatch[0] = *reinterpret_cast<const int*>(e->h_st_host + 2 * fl1);
+        return ORBHIP_OK;
+    }
     const size_t dev_row = ((size_t)width + 15) & ~(size_t)15, dev_frame = dev_row * height;
     HostStage hl, hr;
     int rc = host_staging(left, dev_frame * npairs, true, npairs, cap, &hl);
