@@ -727,6 +727,53 @@ int check_status(orbhip_extractor* e) {
     return ORBHIP_OK;
 }
 
+// The staging block of the host-array entry points (one item per call: a front end's per-frame calls): a device block
+// (d_st_tmp) and its page-locked twin. The inputs are placed in the twin at the offsets of their device arrays and go up
+// in one copy, the outputs come down in one copy each, and one wait ends the call.
+int staged_ensure(orbhip_extractor* e, size_t need) {
+    if (need <= e->d_st_tmp_bytes && need <= e->h_st_tmp_bytes) return ORBHIP_OK;
+    HIP_TRY(e, hipDeviceSynchronize());
+    dfree(e->d_st_tmp);
+    e->d_st_tmp_bytes = 0;
+    if (e->h_st_tmp) (void)hipHostFree(e->h_st_tmp);
+    e->h_st_tmp = nullptr; e->h_st_tmp_bytes = 0;
+    HIP_TRY(e, hipMalloc(&e->d_st_tmp, need));
+    e->d_st_tmp_bytes = need;
+    HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_st_tmp), need, hipHostMallocDefault));
+    e->h_st_tmp_bytes = need;
+    return ORBHIP_OK;
+}
+
+struct Staged {
+    orbhip_extractor* e;
+    uint8_t *d, *h;
+    size_t hi = 0;                                             // end of the inputs placed so far
+    struct Out { void* dst; size_t off, bytes; } outs[6];
+    int nout = 0;
+    explicit Staged(orbhip_extractor* x) : e(x), d(x->d_st_tmp), h(x->h_st_tmp) {}
+    void up(const void* dptr, const void* src, size_t bytes) {
+        const size_t off = (size_t)(static_cast<const uint8_t*>(dptr) - d);
+        if (bytes) std::memcpy(h + off, src, bytes);
+        hi = std::max(hi, off + bytes);
+    }
+    hipError_t send() { return hi ? hipMemcpyAsync(d, h, hi, hipMemcpyHostToDevice, e->stream) : hipSuccess; }
+    void down(void* dst, const void* dptr, size_t bytes) {
+        if (nout < 6) outs[nout++] = Out{dst, (size_t)(static_cast<const uint8_t*>(dptr) - d), bytes};
+    }
+    hipError_t fetch() {
+        for (int i = 0; i < nout; i++)
+            if (outs[i].bytes) {
+                const hipError_t st = hipMemcpyAsync(h + outs[i].off, d + outs[i].off, outs[i].bytes, hipMemcpyDeviceToHost, e->stream);
+                if (st != hipSuccess) return st;
+            }
+        const hipError_t st = hipStreamSynchronize(e->stream);
+        if (st != hipSuccess) return st;
+        for (int i = 0; i < nout; i++)
+            if (outs[i].bytes) std::memcpy(outs[i].dst, h + outs[i].off, outs[i].bytes);
+        return hipSuccess;
+    }
+};
+
 // A thread that is joined when its owner goes out of scope (every return path of the pipelines below).
 struct HelperThread {
     std::thread t;
@@ -2262,29 +2309,25 @@ int orbhip_undistort_grid(orbhip_extractor* e, const orbhip_keypoint* kp, int n,
     const int cap = std::max(n, 1);
     const size_t kpb = (size_t)cap * sizeof(orbhip_keypoint), gsb = (size_t)(GRID_CELLS + 1) * sizeof(int), gib = (size_t)cap * sizeof(int);
     const size_t need = 64 + 2 * kpb + gsb + gib;
-    if (need > e->d_st_tmp_bytes) {
-        HIP_TRY(e, hipDeviceSynchronize());
-        dfree(e->d_st_tmp);
-        HIP_TRY(e, hipMalloc(&e->d_st_tmp, need));
-        e->d_st_tmp_bytes = need;
-    }
+    if (int rc0 = staged_ensure(e, need)) return rc0;
     uint8_t* p = e->d_st_tmp;
+    Staged io(e);
     int* d_cnt = reinterpret_cast<int*>(p); p += 64;
     orbhip_keypoint* d_k = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
     orbhip_keypoint* d_u = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
     int* d_gs = reinterpret_cast<int*>(p); p += gsb;
     int* d_gi = reinterpret_cast<int*>(p);
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipMemcpy(d_cnt, &n, sizeof(int), hipMemcpyHostToDevice));
-    if (n > 0) HIP_TRY(e, hipMemcpy(d_k, kp, (size_t)n * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
+    io.up(d_cnt, &n, sizeof(int));
+    if (n > 0) io.up(d_k, kp, (size_t)n * sizeof(orbhip_keypoint));
+    HIP_TRY(e, io.send());
     int rc = orbhip_undistort_grid_batch_device(e, 1, d_k, d_cnt, cap, cam, bounds, d_u, d_gs, d_gi, nullptr);
     if (rc) return rc;
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
     if (n > 0) {
-        HIP_TRY(e, hipMemcpy(kp_un, d_u, (size_t)n * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost));
-        HIP_TRY(e, hipMemcpy(grid_idx, d_gi, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        io.down(kp_un, d_u, (size_t)n * sizeof(orbhip_keypoint));
+        io.down(grid_idx, d_gi, (size_t)n * sizeof(int));
     }
-    HIP_TRY(e, hipMemcpy(grid_start, d_gs, gsb, hipMemcpyDeviceToHost));
+    io.down(grid_start, d_gs, gsb);
+    HIP_TRY(e, io.fetch());
     return ORBHIP_OK;
 }
 
@@ -2336,13 +2379,9 @@ int orbhip_search_for_initialization(orbhip_extractor* e, const orbhip_keypoint*
     const size_t kpb = (size_t)cap * sizeof(orbhip_keypoint), db = (size_t)cap * 32;
     const size_t pb = (size_t)cap * 2 * sizeof(float), mb = (size_t)cap * sizeof(int);
     const size_t need = 64 + 2 * kpb + 2 * db + pb + mb;
-    if (need > e->d_st_tmp_bytes) {
-        HIP_TRY(e, hipDeviceSynchronize());
-        dfree(e->d_st_tmp);
-        HIP_TRY(e, hipMalloc(&e->d_st_tmp, need));
-        e->d_st_tmp_bytes = need;
-    }
+    if (int rc0 = staged_ensure(e, need)) return rc0;
     uint8_t* p = e->d_st_tmp;
+    Staged io(e);
     int* d_cnt = reinterpret_cast<int*>(p); p += 64;            // [0] n1, [1] n2, [2] matches
     orbhip_keypoint* d_k1 = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
     orbhip_keypoint* d_k2 = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
@@ -2351,22 +2390,22 @@ int orbhip_search_for_initialization(orbhip_extractor* e, const orbhip_keypoint*
     float* d_prev = reinterpret_cast<float*>(p); p += pb;
     int* d_m12 = reinterpret_cast<int*>(p);
     const int cnt[3] = {n1, n2, 0};
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipMemcpy(d_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_k1, kp_un1, (size_t)n1 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_d1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_prev, prev_matched, (size_t)n1 * 2 * sizeof(float), hipMemcpyHostToDevice));
+    io.up(d_cnt, cnt, sizeof(cnt));
+    io.up(d_k1, kp_un1, (size_t)n1 * sizeof(orbhip_keypoint));
+    io.up(d_d1, desc1, (size_t)n1 * 32);
+    io.up(d_prev, prev_matched, (size_t)n1 * 2 * sizeof(float));
     if (n2 > 0) {
-        HIP_TRY(e, hipMemcpy(d_k2, kp_un2, (size_t)n2 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
-        HIP_TRY(e, hipMemcpy(d_d2, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
+        io.up(d_k2, kp_un2, (size_t)n2 * sizeof(orbhip_keypoint));
+        io.up(d_d2, desc2, (size_t)n2 * 32);
     }
+    HIP_TRY(e, io.send());
     int rc = orbhip_search_for_initialization_batch_device(e, 1, d_k1, d_d1, d_cnt, d_k2, d_d2, d_cnt + 1, cap, bounds, d_prev,
                                                            window_size, nnratio, check_orientation, d_m12, d_cnt + 2, nullptr);
     if (rc) return rc;
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipMemcpy(prev_matched, d_prev, (size_t)n1 * 2 * sizeof(float), hipMemcpyDeviceToHost));
-    HIP_TRY(e, hipMemcpy(matches12, d_m12, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost));
-    HIP_TRY(e, hipMemcpy(nmatches, d_cnt + 2, sizeof(int), hipMemcpyDeviceToHost));
+    io.down(prev_matched, d_prev, (size_t)n1 * 2 * sizeof(float));
+    io.down(matches12, d_m12, (size_t)n1 * sizeof(int));
+    io.down(nmatches, d_cnt + 2, sizeof(int));
+    HIP_TRY(e, io.fetch());
     return ORBHIP_OK;
 }
 
@@ -2487,13 +2526,9 @@ int orbhip_search_by_projection(orbhip_extractor* e, const orbhip_keypoint* kp_l
     const size_t kpb = up((size_t)cap * sizeof(orbhip_keypoint)), db = up((size_t)cap * 32), wb = up((size_t)cap * 12);
     const size_t fb = up((size_t)cap), ub = up((size_t)cap * 4), mb = up((size_t)cap * 4);
     const size_t need = 128 + 2 * kpb + 2 * db + wb + fb + ub + mb;
-    if (need > e->d_st_tmp_bytes) {
-        HIP_TRY(e, hipDeviceSynchronize());
-        dfree(e->d_st_tmp);
-        HIP_TRY(e, hipMalloc(&e->d_st_tmp, need));
-        e->d_st_tmp_bytes = need;
-    }
+    if (int rc0 = staged_ensure(e, need)) return rc0;
     uint8_t* p = e->d_st_tmp;
+    Staged io(e);
     int* d_cnt = reinterpret_cast<int*>(p);                     // [0] n1, [1] n2, [2] matches, [3] level mode
     float* d_T = reinterpret_cast<float*>(p + 64); p += 128;
     orbhip_keypoint* d_k1 = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
@@ -2505,22 +2540,22 @@ int orbhip_search_by_projection(orbhip_extractor* e, const orbhip_keypoint* kp_l
     float* d_u = reinterpret_cast<float*>(p); p += ub;
     int* d_m = reinterpret_cast<int*>(p);
     const int cnt[4] = {n1, n2, 0, level_mode};
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipMemcpy(d_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_T, Tcw, 12 * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_k1, kp_last, (size_t)n1 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_d1, desc_last, (size_t)n1 * 32, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_w, world_last, (size_t)n1 * 12, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_f, flags_last, (size_t)n1, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_k2, kp_cur, (size_t)n2 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_d2, desc_cur, (size_t)n2 * 32, hipMemcpyHostToDevice));
-    if (uright_cur) HIP_TRY(e, hipMemcpy(d_u, uright_cur, (size_t)n2 * 4, hipMemcpyHostToDevice));
+    io.up(d_cnt, cnt, sizeof(cnt));
+    io.up(d_T, Tcw, 12 * sizeof(float));
+    io.up(d_k1, kp_last, (size_t)n1 * sizeof(orbhip_keypoint));
+    io.up(d_d1, desc_last, (size_t)n1 * 32);
+    io.up(d_w, world_last, (size_t)n1 * 12);
+    io.up(d_f, flags_last, (size_t)n1);
+    io.up(d_k2, kp_cur, (size_t)n2 * sizeof(orbhip_keypoint));
+    io.up(d_d2, desc_cur, (size_t)n2 * 32);
+    if (uright_cur) io.up(d_u, uright_cur, (size_t)n2 * 4);
+    HIP_TRY(e, io.send());
     int rc = orbhip_search_by_projection_batch_device(e, 1, cap, d_k1, d_w, d_f, d_d1, d_cnt, d_k2, d_d2, uright_cur ? d_u : nullptr,
                                                       d_cnt + 1, d_T, d_cnt + 3, prm, d_m, d_cnt + 2, nullptr);
     if (rc) return rc;
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipMemcpy(match_cur, d_m, (size_t)n2 * sizeof(int), hipMemcpyDeviceToHost));
-    HIP_TRY(e, hipMemcpy(nmatches, d_cnt + 2, sizeof(int), hipMemcpyDeviceToHost));
+    io.down(match_cur, d_m, (size_t)n2 * sizeof(int));
+    io.down(nmatches, d_cnt + 2, sizeof(int));
+    HIP_TRY(e, io.fetch());
     return ORBHIP_OK;
 }
 
@@ -2640,13 +2675,9 @@ int orbhip_search_by_projection_sim3(orbhip_extractor* e, const float* world, co
     const size_t kpb = up((size_t)cap * sizeof(orbhip_keypoint)), db = up((size_t)cap * 32), wb = up((size_t)cap * 12);
     const size_t rb = up((size_t)cap * 8), fb = up((size_t)cap), mb = up((size_t)cap * 4);
     const size_t need = 128 + kpb + 2 * db + 2 * wb + rb + 2 * fb + mb;
-    if (need > e->d_st_tmp_bytes) {
-        HIP_TRY(e, hipDeviceSynchronize());
-        dfree(e->d_st_tmp);
-        HIP_TRY(e, hipMalloc(&e->d_st_tmp, need));
-        e->d_st_tmp_bytes = need;
-    }
+    if (int rc0 = staged_ensure(e, need)) return rc0;
     uint8_t* p = e->d_st_tmp;
+    Staged io(e);
     int* d_cnt = reinterpret_cast<int*>(p);                     // [0] n1, [1] n2, [2] matches
     float* d_T = reinterpret_cast<float*>(p + 64); p += 128;
     orbhip_keypoint* d_k2 = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
@@ -2659,23 +2690,23 @@ int orbhip_search_by_projection_sim3(orbhip_extractor* e, const float* world, co
     uint8_t* d_o = p; p += fb;
     int* d_m = reinterpret_cast<int*>(p);
     const int cnt[3] = {n1, n2, 0};
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipMemcpy(d_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_T, Tcw, 12 * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_d1, desc, (size_t)n1 * 32, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_w, world, (size_t)n1 * 12, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_n, normal, (size_t)n1 * 12, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_r, dist_range, (size_t)n1 * 8, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_f, flags, (size_t)n1, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_k2, kp_kf, (size_t)n2 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_d2, desc_kf, (size_t)n2 * 32, hipMemcpyHostToDevice));
-    if (occupied_kf) HIP_TRY(e, hipMemcpy(d_o, occupied_kf, (size_t)n2, hipMemcpyHostToDevice));
+    io.up(d_cnt, cnt, sizeof(cnt));
+    io.up(d_T, Tcw, 12 * sizeof(float));
+    io.up(d_d1, desc, (size_t)n1 * 32);
+    io.up(d_w, world, (size_t)n1 * 12);
+    io.up(d_n, normal, (size_t)n1 * 12);
+    io.up(d_r, dist_range, (size_t)n1 * 8);
+    io.up(d_f, flags, (size_t)n1);
+    io.up(d_k2, kp_kf, (size_t)n2 * sizeof(orbhip_keypoint));
+    io.up(d_d2, desc_kf, (size_t)n2 * 32);
+    if (occupied_kf) io.up(d_o, occupied_kf, (size_t)n2);
+    HIP_TRY(e, io.send());
     int rc = orbhip_search_by_projection_sim3_batch_device(e, 1, cap, d_w, d_n, d_r, d_f, d_d1, d_cnt, d_k2, d_d2,
                                                            occupied_kf ? d_o : nullptr, d_cnt + 1, d_T, prm, d_m, d_cnt + 2, nullptr);
     if (rc) return rc;
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipMemcpy(match_kf, d_m, (size_t)n2 * sizeof(int), hipMemcpyDeviceToHost));
-    HIP_TRY(e, hipMemcpy(nmatches, d_cnt + 2, sizeof(int), hipMemcpyDeviceToHost));
+    io.down(match_kf, d_m, (size_t)n2 * sizeof(int));
+    io.down(nmatches, d_cnt + 2, sizeof(int));
+    HIP_TRY(e, io.fetch());
     return ORBHIP_OK;
 }
 
@@ -2695,13 +2726,9 @@ int orbhip_search_by_projection_keyframe(orbhip_extractor* e, const orbhip_keypo
     const size_t kpb = up((size_t)cap * sizeof(orbhip_keypoint)), db = up((size_t)cap * 32), wb = up((size_t)cap * 12);
     const size_t rb = up((size_t)cap * 8), fb = up((size_t)cap), mb = up((size_t)cap * 4);
     const size_t need = 128 + 2 * kpb + 2 * db + wb + rb + 2 * fb + mb;
-    if (need > e->d_st_tmp_bytes) {
-        HIP_TRY(e, hipDeviceSynchronize());
-        dfree(e->d_st_tmp);
-        HIP_TRY(e, hipMalloc(&e->d_st_tmp, need));
-        e->d_st_tmp_bytes = need;
-    }
+    if (int rc0 = staged_ensure(e, need)) return rc0;
     uint8_t* p = e->d_st_tmp;
+    Staged io(e);
     int* d_cnt = reinterpret_cast<int*>(p);                     // [0] n1, [1] n2, [2] matches
     float* d_T = reinterpret_cast<float*>(p + 64); p += 128;
     orbhip_keypoint* d_k1 = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
@@ -2714,24 +2741,24 @@ int orbhip_search_by_projection_keyframe(orbhip_extractor* e, const orbhip_keypo
     uint8_t* d_o = p; p += fb;
     int* d_m = reinterpret_cast<int*>(p);
     const int cnt[3] = {n1, n2, 0};
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipMemcpy(d_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_T, Tcw, 12 * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_k1, kp_kf, (size_t)n1 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_d1, desc_kf, (size_t)n1 * 32, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_w, world_kf, (size_t)n1 * 12, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_r, dist_range_kf, (size_t)n1 * 8, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_f, flags_kf, (size_t)n1, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_k2, kp_cur, (size_t)n2 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_d2, desc_cur, (size_t)n2 * 32, hipMemcpyHostToDevice));
-    if (occupied_cur) HIP_TRY(e, hipMemcpy(d_o, occupied_cur, (size_t)n2, hipMemcpyHostToDevice));
+    io.up(d_cnt, cnt, sizeof(cnt));
+    io.up(d_T, Tcw, 12 * sizeof(float));
+    io.up(d_k1, kp_kf, (size_t)n1 * sizeof(orbhip_keypoint));
+    io.up(d_d1, desc_kf, (size_t)n1 * 32);
+    io.up(d_w, world_kf, (size_t)n1 * 12);
+    io.up(d_r, dist_range_kf, (size_t)n1 * 8);
+    io.up(d_f, flags_kf, (size_t)n1);
+    io.up(d_k2, kp_cur, (size_t)n2 * sizeof(orbhip_keypoint));
+    io.up(d_d2, desc_cur, (size_t)n2 * 32);
+    if (occupied_cur) io.up(d_o, occupied_cur, (size_t)n2);
+    HIP_TRY(e, io.send());
     int rc = orbhip_search_by_projection_keyframe_batch_device(e, 1, cap, d_k1, d_w, d_r, d_f, d_d1, d_cnt, d_k2, d_d2,
                                                                occupied_cur ? d_o : nullptr, d_cnt + 1, d_T, prm, orb_dist, d_m,
                                                                d_cnt + 2, nullptr);
     if (rc) return rc;
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipMemcpy(match_cur, d_m, (size_t)n2 * sizeof(int), hipMemcpyDeviceToHost));
-    HIP_TRY(e, hipMemcpy(nmatches, d_cnt + 2, sizeof(int), hipMemcpyDeviceToHost));
+    io.down(match_cur, d_m, (size_t)n2 * sizeof(int));
+    io.down(nmatches, d_cnt + 2, sizeof(int));
+    HIP_TRY(e, io.fetch());
     return ORBHIP_OK;
 }
 
@@ -2810,13 +2837,9 @@ static int search_by_bow_host(orbhip_extractor* e, bool kfkf, const orbhip_keypo
     auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
     const size_t kpb = up((size_t)cap * sizeof(orbhip_keypoint)), db = up((size_t)cap * 32), nb = up((size_t)cap * 4), fb = up((size_t)cap);
     const size_t need = 64 + 2 * kpb + 2 * db + 3 * nb + 2 * fb;
-    if (need > e->d_st_tmp_bytes) {
-        HIP_TRY(e, hipDeviceSynchronize());
-        dfree(e->d_st_tmp);
-        HIP_TRY(e, hipMalloc(&e->d_st_tmp, need));
-        e->d_st_tmp_bytes = need;
-    }
+    if (int rc0 = staged_ensure(e, need)) return rc0;
     uint8_t* p = e->d_st_tmp;
+    Staged io(e);
     int* d_cnt = reinterpret_cast<int*>(p); p += 64;           // [0] n1, [1] n2, [2] matches
     orbhip_keypoint* d_k1 = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
     orbhip_keypoint* d_k2 = reinterpret_cast<orbhip_keypoint*>(p); p += kpb;
@@ -2828,22 +2851,22 @@ static int search_by_bow_host(orbhip_extractor* e, bool kfkf, const orbhip_keypo
     uint8_t* d_f1 = p; p += fb;
     uint8_t* d_f2 = p;
     const int cnt[3] = {n1, n2, 0};
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipMemcpy(d_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_k1, kp1, (size_t)n1 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_d1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_n1, node1, (size_t)n1 * 4, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_f1, flags1, (size_t)n1, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_k2, kp2, (size_t)n2 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_d2, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_n2, node2, (size_t)n2 * 4, hipMemcpyHostToDevice));
-    if (kfkf) HIP_TRY(e, hipMemcpy(d_f2, flags2, (size_t)n2, hipMemcpyHostToDevice));
+    io.up(d_cnt, cnt, sizeof(cnt));
+    io.up(d_k1, kp1, (size_t)n1 * sizeof(orbhip_keypoint));
+    io.up(d_d1, desc1, (size_t)n1 * 32);
+    io.up(d_n1, node1, (size_t)n1 * 4);
+    io.up(d_f1, flags1, (size_t)n1);
+    io.up(d_k2, kp2, (size_t)n2 * sizeof(orbhip_keypoint));
+    io.up(d_d2, desc2, (size_t)n2 * 32);
+    io.up(d_n2, node2, (size_t)n2 * 4);
+    if (kfkf) io.up(d_f2, flags2, (size_t)n2);
+    HIP_TRY(e, io.send());
     int rc = search_by_bow_launch(e, kfkf, 1, cap, d_k1, d_d1, d_n1, d_f1, d_cnt, d_k2, d_d2, d_n2, kfkf ? d_f2 : nullptr, d_cnt + 1,
                                   nnratio, check_orientation, d_m, d_cnt + 2, nullptr);
     if (rc) return rc;
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipMemcpy(match, d_m, (size_t)nout * sizeof(int), hipMemcpyDeviceToHost));
-    HIP_TRY(e, hipMemcpy(nmatches, d_cnt + 2, sizeof(int), hipMemcpyDeviceToHost));
+    io.down(match, d_m, (size_t)nout * sizeof(int));
+    io.down(nmatches, d_cnt + 2, sizeof(int));
+    HIP_TRY(e, io.fetch());
     return ORBHIP_OK;
 }
 
@@ -2911,13 +2934,9 @@ int orbhip_search_map_points(orbhip_extractor* e, const orbhip_track_point* mp, 
     const size_t tb = up((size_t)n1 * sizeof(orbhip_track_point)), d1b = up((size_t)n1 * 32);
     const size_t kpb = up((size_t)n2 * sizeof(orbhip_keypoint)), d2b = up((size_t)n2 * 32), ub = up((size_t)n2 * 4), ob = up((size_t)n2);
     const size_t need = 64 + tb + d1b + kpb + d2b + 2 * ub + ob;
-    if (need > e->d_st_tmp_bytes) {
-        HIP_TRY(e, hipDeviceSynchronize());
-        dfree(e->d_st_tmp);
-        HIP_TRY(e, hipMalloc(&e->d_st_tmp, need));
-        e->d_st_tmp_bytes = need;
-    }
+    if (int rc0 = staged_ensure(e, need)) return rc0;
     uint8_t* p = e->d_st_tmp;
+    Staged io(e);
     int* d_cnt = reinterpret_cast<int*>(p); p += 64;           // [0] n1, [1] n2, [2] matches
     orbhip_track_point* d_t = reinterpret_cast<orbhip_track_point*>(p); p += tb;
     uint8_t* d_d1 = p; p += d1b;
@@ -2927,20 +2946,20 @@ int orbhip_search_map_points(orbhip_extractor* e, const orbhip_track_point* mp, 
     int* d_m = reinterpret_cast<int*>(p); p += ub;
     uint8_t* d_o = p;
     const int cnt[3] = {n1, n2, 0};
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipMemcpy(d_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_t, mp, (size_t)n1 * sizeof(orbhip_track_point), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_d1, desc_mp, (size_t)n1 * 32, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_k, kp, (size_t)n2 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_d2, desc, (size_t)n2 * 32, hipMemcpyHostToDevice));
-    if (uright) HIP_TRY(e, hipMemcpy(d_u, uright, (size_t)n2 * 4, hipMemcpyHostToDevice));
-    if (occupied) HIP_TRY(e, hipMemcpy(d_o, occupied, (size_t)n2, hipMemcpyHostToDevice));
+    io.up(d_cnt, cnt, sizeof(cnt));
+    io.up(d_t, mp, (size_t)n1 * sizeof(orbhip_track_point));
+    io.up(d_d1, desc_mp, (size_t)n1 * 32);
+    io.up(d_k, kp, (size_t)n2 * sizeof(orbhip_keypoint));
+    io.up(d_d2, desc, (size_t)n2 * 32);
+    if (uright) io.up(d_u, uright, (size_t)n2 * 4);
+    if (occupied) io.up(d_o, occupied, (size_t)n2);
+    HIP_TRY(e, io.send());
     int rc = orbhip_search_map_points_batch_device(e, 1, n1, d_t, d_d1, d_cnt, n2, d_k, d_d2, uright ? d_u : nullptr,
                                                    occupied ? d_o : nullptr, d_cnt + 1, bounds, th, nnratio, d_m, d_cnt + 2, nullptr);
     if (rc) return rc;
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipMemcpy(match, d_m, (size_t)n2 * sizeof(int), hipMemcpyDeviceToHost));
-    HIP_TRY(e, hipMemcpy(nmatches, d_cnt + 2, sizeof(int), hipMemcpyDeviceToHost));
+    io.down(match, d_m, (size_t)n2 * sizeof(int));
+    io.down(nmatches, d_cnt + 2, sizeof(int));
+    HIP_TRY(e, io.fetch());
     return ORBHIP_OK;
 }
 
@@ -2985,26 +3004,22 @@ int orbhip_is_in_frustum(orbhip_extractor* e, const orbhip_map_point* mp, int n,
     auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
     const size_t mb = up((size_t)n * sizeof(orbhip_map_point)), tb = up((size_t)n * sizeof(orbhip_track_point));
     const size_t need = 128 + mb + tb;
-    if (need > e->d_st_tmp_bytes) {
-        HIP_TRY(e, hipDeviceSynchronize());
-        dfree(e->d_st_tmp);
-        HIP_TRY(e, hipMalloc(&e->d_st_tmp, need));
-        e->d_st_tmp_bytes = need;
-    }
+    if (int rc0 = staged_ensure(e, need)) return rc0;
     uint8_t* p = e->d_st_tmp;
+    Staged io(e);
     int* d_cnt = reinterpret_cast<int*>(p);                     // [0] n, [1] visible
     float* d_pose = reinterpret_cast<float*>(p + 64); p += 128;
     orbhip_map_point* d_m = reinterpret_cast<orbhip_map_point*>(p); p += mb;
     orbhip_track_point* d_t = reinterpret_cast<orbhip_track_point*>(p);
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipMemcpy(d_cnt, &n, sizeof(int), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_pose, pose, 15 * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(d_m, mp, (size_t)n * sizeof(orbhip_map_point), hipMemcpyHostToDevice));
+    io.up(d_cnt, &n, sizeof(int));
+    io.up(d_pose, pose, 15 * sizeof(float));
+    io.up(d_m, mp, (size_t)n * sizeof(orbhip_map_point));
+    HIP_TRY(e, io.send());
     int rc = orbhip_is_in_frustum_batch_device(e, 1, n, d_m, d_cnt, d_pose, prm, viewing_cos_limit, d_t, d_cnt + 1, nullptr);
     if (rc) return rc;
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipMemcpy(track, d_t, (size_t)n * sizeof(orbhip_track_point), hipMemcpyDeviceToHost));
-    if (nvisible) HIP_TRY(e, hipMemcpy(nvisible, d_cnt + 1, sizeof(int), hipMemcpyDeviceToHost));
+    io.down(track, d_t, (size_t)n * sizeof(orbhip_track_point));
+    if (nvisible) io.down(nvisible, d_cnt + 1, sizeof(int));
+    HIP_TRY(e, io.fetch());
     return ORBHIP_OK;
 }
 
